@@ -1,0 +1,199 @@
+/* talc_hip.h — C ABI of libtalc_hip.so, the MI355X-native replacement of TALC's per-long-read
+ * correction hot path (reference: lbroseus/TALC 1.01, paths below are under /root/reference/src).
+ *
+ * TALC has no plugin/FFI API; the seam this library sits behind is made of two C++ call
+ * surfaces of the reference:
+ *   (1) the k-mer table surface   Jellyfish.hpp:42-71  + utils.hpp:145
+ *   (2) the per-read surface      Read.hpp:43-77, driven by main.cpp:247-308
+ * Each entry point below cites the reference interface it replaces.  Plain pointers and sizes
+ * only; no C++ or torch types cross the boundary; no exceptions cross the boundary.
+ *
+ * Error convention (replaces the reference's bool returns / throw std::string,
+ * Read.cpp:194,275, main.cpp:298-303): every function returns 0 on success or a negative
+ * talc_error; talc_last_error() returns a human-readable message for the calling thread.
+ * Per-read outcomes are reported in a status array so the caller can emit the reference's log
+ * lines verbatim (main.cpp:290,294).
+ *
+ * Threading (reference: any number of OpenMP threads on one shared read-only map,
+ * main.cpp:247): a talc_table is immutable after talc_table_upload and may be shared by any
+ * number of contexts; a talc_ctx is bound to one device + one HIP stream and must be used by
+ * one host thread at a time.
+ */
+#ifndef TALC_HIP_H
+#define TALC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TALC_ABI_VERSION 1
+
+typedef enum talc_error {
+  TALC_OK = 0,
+  TALC_ERR_INVALID = -1,     /* bad argument / parameter out of the supported range */
+  TALC_ERR_IO = -2,          /* cannot open / parse an input file */
+  TALC_ERR_NOMEM = -3,       /* host or device allocation failed */
+  TALC_ERR_DEVICE = -4,      /* HIP runtime error (no GPU, launch failure, ...) */
+  TALC_ERR_CAPACITY = -5,    /* caller-provided output buffer too small (needed size reported) */
+  TALC_ERR_STATE = -6        /* call sequence error (e.g. table not uploaded) */
+} talc_error;
+
+/* Per-read status after the main.cpp:247-308 loop body. */
+typedef enum talc_read_status {
+  TALC_READ_CORRECTED = 0,      /* main.cpp:277-286: corrected sequence returned */
+  TALC_READ_SKIPPED_SHORT = 1,  /* main.cpp:262: length <= K; passed through, no log line */
+  TALC_READ_NO_SOLID_KMER = 2,  /* main.cpp:294: log "No solid kmer could be found." */
+  TALC_READ_NO_STRUCTURE = 3,   /* main.cpp:290: log "Unable to define convenient structure." */
+  TALC_READ_ERROR = 4           /* device scratch exhausted even after the retry pass; the read is
+                                   passed through unchanged and the batch call returns an error */
+} talc_read_status;
+
+/* The reference's process globals (Settings.cpp:33-63) plus its hard-coded tunables
+ * (Explorer.cpp:85-102, Jellyfish.cpp:64, Read.cpp:361,368) as one POD.  Field meaning and
+ * defaults are the reference's; talc_params_default() fills them. */
+typedef struct talc_params {
+  uint32_t k;                       /* K, -k; 18..31 (reference CLI stops at 30, main.cpp:115) */
+  uint32_t min_count;               /* gp_MIN_COUNT, --MIN_COUNT (2) */
+  double alpha;                     /* gp_ALPHA, --ALPHA_FOR_PRED (2.57) */
+  uint32_t window_size;             /* gp_WINDOW_SIZE, --WINDOW_SIZE (9) */
+  double sr_error_rate;             /* gp_SR_ERROR_RATE, --SR_ERROR_RATE (0.025) */
+  double min_inner_score;           /* gp_MIN_INNER_SCORE (0.7) */
+  double min_border_score;          /* gp_MIN_BORDER_SCORE (0.7) */
+  uint32_t max_nb_competing_paths;  /* gp_MAX_NB_COMPETING_PATHS, --MAX_NB_BRANCHES (7) */
+  int32_t use_junctions;            /* gp_useJunctions: informational; colouring is explicit */
+  int32_t reverse;                  /* gp_reverse, -rev */
+  uint32_t min_start_anchors;       /* p_MIN_START_ANCHORS (3)        Explorer.cpp:85 */
+  uint32_t max_start_anchors;       /* p_MAX_START_ANCHORS (5)        Explorer.cpp:86 */
+  uint32_t max_in_count;            /* p_MAX_IN_COUNT (100000)        Explorer.cpp:88 */
+  uint32_t max_nb_border_paths;     /* p_MAX_NB_OF_BORDER_PATHS (75)  Explorer.cpp:90 */
+  uint32_t max_nb_inner_paths;      /* p_MAX_NB_OF_INNER_PATHS (50)   Explorer.cpp:91 */
+  uint32_t check_interval;          /* p_CHECK_INTERVAL (6)           Explorer.cpp:93 */
+  double allowed_failure_rate;      /* p_ALLOWED_FAILURE_RATE (0.3)   Explorer.cpp:94 */
+  int32_t max_nb_border_failures;   /* p_MAX_NB_BORDER_FAILURES (3)   Explorer.cpp:97 */
+  uint32_t coloured_count_thr;      /* colouredCountThr (10000)       Jellyfish.cpp:64; <= 65535 */
+  uint32_t max_border_length;       /* head/tail limit (500)          Read.cpp:361,368 */
+} talc_params;
+
+typedef struct talc_table talc_table;   /* the SR k-mer table ("SR-dBG", Settings.cpp:50) */
+typedef struct talc_ctx talc_ctx;       /* one device + stream + scratch */
+typedef struct talc_batch talc_batch;   /* a batch of reads resident in HBM */
+
+int talc_abi_version(void);
+const char* talc_last_error(void);
+int talc_params_default(talc_params* p);
+/* number of visible HIP devices (0 when there is no GPU); never initialises a device */
+int talc_device_count(void);
+
+/* ---------------------------------------------------------------- (1) table surface ------
+ * Replaces  colouredDBG buildCDBG(int, string& dump, string& junctionDump)   Jellyfish.cpp:236-295
+ *           void decolourRepeatsFromDBG(colouredDBG&, K)                     utils.cpp:658-669
+ * k-mers are directional (non-canonical, main.cpp:89).  Packed k-mers are 2 bits per base
+ * (A=0,C=1,G=2,T=3), first base in the most significant position of the 2K-bit value. */
+
+/* Parse a `jellyfish dump -c` text file ("KMER count" per line, whitespace separated,
+ * Jellyfish.cpp:251-269): keeps lines with count >= min_count, first duplicate wins; then,
+ * if junction_path is not NULL, colours k-mers from the junction dump (both strands,
+ * jcount < coloured_count_thr, Jellyfish.cpp:273-290); then un-colours the 4 homopolymer
+ * k-mers (utils.cpp:658-669).  Lines whose k-mer is not K letters of ACGT can never match a
+ * query and are counted in stats but not stored.  stats (may be NULL) receives
+ * {lines read, lines kept, malformed lines}. */
+int talc_table_build(const char* dump_path, const char* junction_path, const talc_params* p,
+                     talc_table** out, int64_t stats[3]);
+
+/* Same build from arrays (dump order = array order; the count >= min_count filter and the
+ * first-duplicate-wins rule are applied here).  No colouring, no de-colouring. */
+int talc_table_from_arrays(const uint64_t* kmers, const uint32_t* counts, uint64_t n,
+                           const talc_params* p, talc_table** out);
+/* Junction colouring on arrays, in order, both strands (Jellyfish.cpp:278-289). */
+int talc_table_colour(talc_table* t, const uint64_t* jkmers, const int64_t* jcounts, uint64_t n);
+/* decolourRepeatsFromDBG (utils.cpp:658-669). */
+int talc_table_decolour_repeats(talc_table* t);
+
+uint64_t talc_table_size(const talc_table* t);        /* SR_DBG.size() (main.cpp:237) */
+uint64_t talc_table_device_bytes(const talc_table* t);
+
+/* Copy the table to `device` (HBM resident, replicated per GPU).  The table becomes
+ * immutable.  May be called once per device. */
+int talc_table_upload(talc_table* t, int device);
+
+/* Test hooks on the uploaded table — the reference's point queries:
+ *   getCount(kmer)               Jellyfish.cpp:397-413  -> (count, junction colour) or (0,0)
+ *   getNextCounts(kmer, dir)     Jellyfish.cpp:299-321  -> 4 x (count, colour), order A,C,G,T
+ * direction: 0 = LEFT, 1 = RIGHT (utils.hpp:56).  Host pointers. */
+int talc_table_lookup_batch(talc_table* t, int device, const uint64_t* kmers, uint64_t n,
+                            uint32_t* counts, uint32_t* jcounts);
+int talc_table_next_counts_batch(talc_table* t, int device, const uint64_t* kmers, uint64_t n,
+                                 int direction, uint32_t* counts4, uint32_t* jcounts4);
+void talc_table_destroy(talc_table* t);
+
+/* ---------------------------------------------------------------- (2) per-read surface ---
+ * Replaces, for a whole batch, the loop body of main.cpp:247-308:
+ *   Read(id, seq); getLength()>K; reCoverage(); defineStructure2(); correct2(); getCorrSeq()
+ * (Read.hpp:43-77) including the -rev handling of main.cpp:253,286. */
+
+int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** out);
+void talc_ctx_destroy(talc_ctx* c);
+
+/* Upload a batch: `bases` are raw characters (any case; anything but ACGT becomes N exactly
+ * like SeqAn's Dna5 conversion), concatenated; offsets[n_reads+1].  Caller-owned, not retained. */
+int talc_batch_create(talc_ctx* c, const char* bases, const uint64_t* offsets, uint32_t n_reads,
+                      talc_batch** out);
+void talc_batch_destroy(talc_batch* b);
+
+/* Read::reCoverage (Read.cpp:174-195) for every read of the batch: the k-mer probe kernel.
+ * Results stay on the device; talc_batch_fetch_coverage copies them out. */
+int talc_batch_coverage(talc_ctx* c, talc_batch* b);
+/* counts/jcounts: one entry per k-mer, reads concatenated (read r contributes max(0,L_r-K+1)
+ * entries); kmer_offsets[n_reads+1] (may be NULL); n_in_kmers[n_reads] = #{count > min_count}
+ * (Read.cpp:190, may be NULL). */
+int talc_batch_fetch_coverage(talc_ctx* c, talc_batch* b, uint32_t* counts, uint32_t* jcounts,
+                              uint64_t* kmer_offsets, int32_t* n_in_kmers);
+uint64_t talc_batch_num_kmers(const talc_batch* b);
+uint64_t talc_batch_num_bases(const talc_batch* b);
+
+/* The whole hot path on the device: coverage -> structure (defineStructure2) -> path search
+ * (correct2) -> reassembly.  Synchronous: returns when the corrected records are in HBM. */
+int talc_batch_correct(talc_ctx* c, talc_batch* b);
+/* Total corrected size (bytes) so the caller can allocate; valid after talc_batch_correct. */
+uint64_t talc_batch_corrected_bytes(const talc_batch* b);
+/* out: corrected (or passed-through) sequences as upper-case ACGTN text, concatenated in input
+ * order; out_offsets[n_reads+1]; status[n_reads] (talc_read_status).  Reads that were not
+ * corrected are returned exactly as the reference leaves mySeqs[r] (Dna5-converted; still
+ * reverse-complemented under -rev, main.cpp:253 vs :286). */
+int talc_batch_fetch_corrected(talc_ctx* c, talc_batch* b, char* out, uint64_t out_capacity,
+                               uint64_t* out_offsets, int32_t* status);
+
+/* Convenience: create + correct + fetch + destroy. */
+int talc_correct_batch(talc_ctx* c, const char* bases, const uint64_t* offsets, uint32_t n_reads,
+                       char* out, uint64_t out_capacity, uint64_t* out_offsets, int32_t* status);
+
+/* ---------------------------------------------------------------- measurement -----------
+ * HIP-event timings (ms) of the kernels launched by the last talc_batch_coverage /
+ * talc_batch_correct call on this context's stream, and work counters. */
+typedef struct talc_timing {
+  float encode_ms;        /* ASCII -> Dna5 codes (+ reverse complement) */
+  float coverage_ms;      /* k-mer probe kernel (a4) */
+  float structure_ms;     /* defineStructure2 kernel (a5-a9) */
+  float search_ms;        /* path-search kernel (a10-a22) */
+  float emit_ms;          /* reassembly / output kernel */
+  float retry_ms;         /* second pass for reads whose scratch overflowed */
+  uint64_t n_kmers;       /* k-mers probed by the coverage kernel */
+  uint64_t n_bases;       /* raw bases in the batch */
+  uint64_t n_trail_steps; /* successor probes issued by the search kernel (Trail-steps) */
+  uint64_t n_dp_cells;    /* DP cells evaluated by the search kernel */
+  uint32_t n_retried;     /* reads that needed the big-scratch retry pass */
+  uint32_t n_failed;      /* reads with TALC_READ_ERROR */
+} talc_timing;
+int talc_ctx_get_timing(const talc_ctx* c, talc_timing* out);
+
+/* Debug hook: textual trace of one read of a batch (regions, anchors, per-gap results) in the
+ * same line format as the test oracle's trace; used to localise divergences.  Returns the
+ * number of bytes needed (including the NUL). */
+int64_t talc_batch_trace_read(talc_ctx* c, talc_batch* b, uint32_t read_index, char* buf, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TALC_HIP_H */

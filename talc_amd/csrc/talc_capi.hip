@@ -1,0 +1,465 @@
+// talc_capi.hip — the C ABI of libtalc_hip.so (include/talc_hip.h): host orchestration of the
+// GPU k-mer table and of the per-read correction kernels.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "talc_common.h"
+#include "talc_hip.h"
+#include "talc_kernels_probe.h"
+#include "talc_kernels_search.h"
+#include "talc_table_host.h"
+
+using namespace talc;
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t _e = (x);                                                                   \
+    if (_e != hipSuccess) return fail(TALC_ERR_DEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+struct talc_table {
+  HostTable h;
+};
+
+struct Stage {
+  // per-wave scratch for the search kernel
+  uint8_t* scratch = nullptr;
+  uint64_t scratch_bytes = 0;
+  uint32_t n_slots = 0;
+  SearchCaps caps;
+};
+
+struct talc_ctx {
+  talc_table* table = nullptr;
+  talc_params p;
+  DevParams dp;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8];
+  TableView view;
+  talc_timing timing;
+  Stage stage;          // default scratch
+  uint32_t* d_queue = nullptr;   // work-queue counters
+  uint64_t* d_counters = nullptr;  // [0]=trail steps [1]=dp cells
+};
+
+struct talc_batch {
+  talc_ctx* ctx = nullptr;
+  uint32_t n_reads = 0;
+  uint64_t n_bases = 0, n_kmers = 0;
+  uint32_t max_len = 0;
+  std::vector<uint64_t> h_offsets, h_koff;
+  std::vector<uint32_t> h_tile_read, h_tile_start, h_chunk_read, h_chunk_start, h_order;
+  uint8_t* d_raw = nullptr;
+  uint8_t* d_codes = nullptr;
+  uint64_t* d_offsets = nullptr;
+  uint64_t* d_koff = nullptr;
+  uint32_t *d_tile_read = nullptr, *d_tile_start = nullptr, *d_chunk_read = nullptr, *d_chunk_start = nullptr;
+  uint32_t* d_order = nullptr;
+  uint2* d_cov = nullptr;
+  int32_t* d_nin = nullptr;
+  // structure + results
+  ReadState* d_state = nullptr;
+  uint32_t* d_regions = nullptr;     // 2 x u32 per region slot
+  uint64_t* d_regoff = nullptr;      // per-read offset (in regions) into d_regions
+  std::vector<uint64_t> h_regoff;
+  uint8_t* d_out = nullptr;          // corrected codes, per-read capacity slots
+  uint64_t* d_outoff = nullptr;      // per-read offset into d_out
+  std::vector<uint64_t> h_outoff;
+  uint64_t out_capacity = 0;
+  bool encoded = false, covered = false, corrected = false;
+  std::vector<ReadState> h_state;
+  std::vector<uint64_t> h_dense_off;
+  uint8_t* d_dense = nullptr;
+  uint64_t* d_dense_off = nullptr;
+};
+
+template <typename T>
+static int up(T** d, const std::vector<T>& h, hipStream_t s) {
+  size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc((void**)d, bytes));
+  if (!h.empty()) HIPCHK(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return TALC_OK;
+}
+
+extern "C" {
+
+int talc_abi_version(void) { return TALC_ABI_VERSION; }
+const char* talc_last_error(void) { return g_err.c_str(); }
+
+int talc_params_default(talc_params* p) {
+  if (!p) return fail(TALC_ERR_INVALID, "null params");
+  p->k = 21; p->min_count = 2; p->alpha = 2.57; p->window_size = 9; p->sr_error_rate = 0.025;
+  p->min_inner_score = 0.7; p->min_border_score = 0.7; p->max_nb_competing_paths = 7; p->use_junctions = 0;
+  p->reverse = 0; p->min_start_anchors = 3; p->max_start_anchors = 5; p->max_in_count = 100000;
+  p->max_nb_border_paths = 75; p->max_nb_inner_paths = 50; p->check_interval = 6; p->allowed_failure_rate = 0.3;
+  p->max_nb_border_failures = 3; p->coloured_count_thr = 10000; p->max_border_length = 500;
+  return TALC_OK;
+}
+
+int talc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+static int check_params(const talc_params* p) {
+  if (!p) return fail(TALC_ERR_INVALID, "null params");
+  if (p->k < 18 || p->k > 31) return fail(TALC_ERR_INVALID, "k=%u outside the supported range 18..31", p->k);
+  if (p->min_count < 1) return fail(TALC_ERR_INVALID, "min_count must be >= 1 (reference CLI: >= 2)");
+  if (p->coloured_count_thr > 65535) return fail(TALC_ERR_INVALID, "coloured_count_thr must be <= 65535");
+  if (p->max_nb_competing_paths < 1 || p->max_nb_competing_paths > 64) return fail(TALC_ERR_INVALID, "max_nb_competing_paths must be in 1..64");
+  if (p->max_nb_inner_paths < 1 || p->max_nb_inner_paths > 60) return fail(TALC_ERR_INVALID, "max_nb_inner_paths must be in 1..60");
+  if (p->max_start_anchors < 1 || p->max_start_anchors > 64) return fail(TALC_ERR_INVALID, "max_start_anchors must be in 1..64");
+  if (p->check_interval < 1) return fail(TALC_ERR_INVALID, "check_interval must be >= 1");
+  if (!(p->sr_error_rate > 0)) return fail(TALC_ERR_INVALID, "sr_error_rate must be > 0");
+  return TALC_OK;
+}
+
+// ------------------------------------------------------------------ table
+int talc_table_from_arrays(const uint64_t* kmers, const uint32_t* counts, uint64_t n, const talc_params* p,
+                           talc_table** out) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!out || (n && (!kmers || !counts))) return fail(TALC_ERR_INVALID, "null argument");
+  uint64_t kept = 0;
+#pragma omp parallel for reduction(+ : kept)
+  for (long i = 0; i < (long)n; ++i) kept += counts[i] >= p->min_count ? 1 : 0;
+  talc_table* t = new talc_table();
+  t->h.p = *p;
+  if (!t->h.allocate(kept)) { delete t; return fail(TALC_ERR_NOMEM, "cannot allocate host table for %llu k-mers", (unsigned long long)kept); }
+  t->h.insertAll(kmers, counts, n);
+  *out = t;
+  return TALC_OK;
+}
+
+int talc_table_build(const char* dump_path, const char* junction_path, const talc_params* p, talc_table** out,
+                     int64_t stats[3]) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!dump_path || !out) return fail(TALC_ERR_INVALID, "null argument");
+  // Jellyfish.cpp:251-269: whitespace-separated "kmer count" per line
+  FILE* f = fopen(dump_path, "r");
+  if (!f) return fail(TALC_ERR_IO, "cannot open %s", dump_path);
+  std::vector<uint64_t> kmers;
+  std::vector<uint32_t> counts;
+  int64_t nread = 0, nkept = 0, nbad = 0;
+  char line[4096], km[2048], cs[2048];
+  while (fgets(line, sizeof line, f)) {
+    if (sscanf(line, "%2047s %2047s", km, cs) == 2) {
+      int c = atoi(cs);  // std::stoi in the reference
+      nread++;
+      if ((unsigned int)c >= p->min_count) {  // int vs unsigned compare (Jellyfish.cpp:260)
+        nkept++;
+        uint64_t packed;
+        // k-mers that are not K letters of ACGT can never equal a read k-mer's text unless the
+        // read k-mer has N at the same places; those are not representable and are dropped.
+        if (packText(km, strlen(km), p->k, packed)) { kmers.push_back(packed); counts.push_back((uint32_t)c); }
+      }
+    } else {
+      nbad++;
+    }
+  }
+  fclose(f);
+  talc_table* t = nullptr;
+  rc = talc_table_from_arrays(kmers.data(), counts.data(), kmers.size(), p, &t);
+  if (rc) return rc;
+  std::vector<uint64_t>().swap(kmers);
+  std::vector<uint32_t>().swap(counts);
+  if (junction_path && junction_path[0]) {  // Jellyfish.cpp:273-290
+    FILE* jf = fopen(junction_path, "r");
+    if (!jf) { delete t; return fail(TALC_ERR_IO, "cannot open %s", junction_path); }
+    std::vector<uint64_t> jk;
+    std::vector<int64_t> jc;
+    while (fgets(line, sizeof line, jf)) {
+      if (sscanf(line, "%2047s %2047s", km, cs) == 2) {
+        uint64_t packed;
+        if (packText(km, strlen(km), p->k, packed)) { jk.push_back(packed); jc.push_back((int64_t)atoi(cs)); }
+      } else
+        nbad++;
+    }
+    fclose(jf);
+    t->h.colour(jk.data(), jc.data(), jk.size());
+  }
+  t->h.decolourRepeats();  // main.cpp:232
+  if (stats) { stats[0] = nread; stats[1] = nkept; stats[2] = nbad; }
+  *out = t;
+  return TALC_OK;
+}
+
+int talc_table_colour(talc_table* t, const uint64_t* jkmers, const int64_t* jcounts, uint64_t n) {
+  if (!t || (n && (!jkmers || !jcounts))) return fail(TALC_ERR_INVALID, "null argument");
+  if (t->h.frozen) return fail(TALC_ERR_STATE, "table already uploaded (immutable)");
+  t->h.colour(jkmers, jcounts, n);
+  return TALC_OK;
+}
+int talc_table_decolour_repeats(talc_table* t) {
+  if (!t) return fail(TALC_ERR_INVALID, "null argument");
+  if (t->h.frozen) return fail(TALC_ERR_STATE, "table already uploaded (immutable)");
+  t->h.decolourRepeats();
+  return TALC_OK;
+}
+uint64_t talc_table_size(const talc_table* t) { return t ? t->h.nkmers : 0; }
+uint64_t talc_table_device_bytes(const talc_table* t) { return t ? 2 * t->h.capacity * sizeof(Bucket) : 0; }
+
+int talc_table_upload(talc_table* t, int device) {
+  if (!t) return fail(TALC_ERR_INVALID, "null table");
+  if (t->h.dev.count(device)) return TALC_OK;
+  if (!t->h.right) return fail(TALC_ERR_STATE, "host image already released");
+  HIPCHK(hipSetDevice(device));
+  DeviceCopy dc;
+  const uint64_t bytes = t->h.capacity * sizeof(Bucket);
+  HIPCHK(hipMalloc((void**)&dc.right, bytes));
+  HIPCHK(hipMalloc((void**)&dc.left, bytes));
+  HIPCHK(hipMemcpy(dc.right, t->h.right, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dc.left, t->h.left, bytes, hipMemcpyHostToDevice));
+  t->h.dev[device] = dc;
+  t->h.frozen = true;
+  return TALC_OK;
+}
+
+static int table_view(talc_table* t, int device, TableView& v) {
+  auto it = t->h.dev.find(device);
+  if (it == t->h.dev.end()) return fail(TALC_ERR_STATE, "table not uploaded to device %d", device);
+  v.right = it->second.right; v.left = it->second.left; v.capacity = t->h.capacity; v.k = t->h.p.k;
+  return TALC_OK;
+}
+
+int talc_table_lookup_batch(talc_table* t, int device, const uint64_t* kmers, uint64_t n, uint32_t* counts,
+                            uint32_t* jcounts) {
+  if (!t || !kmers || !counts || !jcounts) return fail(TALC_ERR_INVALID, "null argument");
+  TableView v;
+  int rc = table_view(t, device, v);
+  if (rc) return rc;
+  if (n == 0) return TALC_OK;
+  HIPCHK(hipSetDevice(device));
+  uint64_t* dk; uint32_t *dc, *dj;
+  HIPCHK(hipMalloc((void**)&dk, n * 8)); HIPCHK(hipMalloc((void**)&dc, n * 4)); HIPCHK(hipMalloc((void**)&dj, n * 4));
+  HIPCHK(hipMemcpy(dk, kmers, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, dk, n, dc, dj);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(counts, dc, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(jcounts, dj, n * 4, hipMemcpyDeviceToHost));
+  hipFree(dk); hipFree(dc); hipFree(dj);
+  return TALC_OK;
+}
+
+int talc_table_next_counts_batch(talc_table* t, int device, const uint64_t* kmers, uint64_t n, int direction,
+                                 uint32_t* counts4, uint32_t* jcounts4) {
+  if (!t || !kmers || !counts4 || !jcounts4) return fail(TALC_ERR_INVALID, "null argument");
+  TableView v;
+  int rc = table_view(t, device, v);
+  if (rc) return rc;
+  if (n == 0) return TALC_OK;
+  HIPCHK(hipSetDevice(device));
+  uint64_t* dk; uint32_t *dc, *dj;
+  HIPCHK(hipMalloc((void**)&dk, n * 8)); HIPCHK(hipMalloc((void**)&dc, n * 16)); HIPCHK(hipMalloc((void**)&dj, n * 16));
+  HIPCHK(hipMemcpy(dk, kmers, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_next_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, dk, n, direction ? 1 : 0, dc, dj);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(counts4, dc, n * 16, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(jcounts4, dj, n * 16, hipMemcpyDeviceToHost));
+  hipFree(dk); hipFree(dc); hipFree(dj);
+  return TALC_OK;
+}
+
+void talc_table_destroy(talc_table* t) {
+  if (!t) return;
+  for (auto& kv : t->h.dev) {
+    if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.right); hipFree(kv.second.left); }
+  }
+  delete t;
+}
+
+// ------------------------------------------------------------------ context
+static void free_stage(Stage& s) { if (s.scratch) hipFree(s.scratch); s = Stage(); }
+
+int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** out) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!t || !out) return fail(TALC_ERR_INVALID, "null argument");
+  if (p->k != t->h.p.k) return fail(TALC_ERR_INVALID, "k mismatch between params (%u) and table (%u)", p->k, t->h.p.k);
+  TableView v;
+  rc = table_view(t, device, v);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(device));
+  talc_ctx* c = new talc_ctx();
+  c->table = t; c->p = *p; c->device = device; c->view = v;
+  memset(&c->timing, 0, sizeof c->timing);
+  DevParams& d = c->dp;
+  d.K = p->k; d.MIN_COUNT = p->min_count; d.ALPHA = p->alpha; d.WINDOW = p->window_size; d.ERR = p->sr_error_rate;
+  d.MIN_INNER = p->min_inner_score; d.MIN_BORDER = p->min_border_score; d.MAXB = p->max_nb_competing_paths;
+  d.reverse = p->reverse; d.MIN_START_ANCHORS = p->min_start_anchors; d.MAX_START_ANCHORS = p->max_start_anchors;
+  d.MAX_IN_COUNT = p->max_in_count; d.MAX_BORDER_PATHS = p->max_nb_border_paths; d.MAX_INNER_PATHS = p->max_nb_inner_paths;
+  d.CHECK_INTERVAL = p->check_interval; d.FAILURE_RATE = p->allowed_failure_rate;
+  d.MAX_BORDER_FAILURES = p->max_nb_border_failures; d.MAX_BORDER_LEN = p->max_border_length;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&c->d_counters, 16 * sizeof(uint64_t)));
+  *out = c;
+  return TALC_OK;
+}
+
+void talc_ctx_destroy(talc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  free_stage(c->stage);
+  if (c->d_queue) hipFree(c->d_queue);
+  if (c->d_counters) hipFree(c->d_counters);
+  for (auto& e : c->ev) if (e) hipEventDestroy(e);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int talc_ctx_get_timing(const talc_ctx* c, talc_timing* out) {
+  if (!c || !out) return fail(TALC_ERR_INVALID, "null argument");
+  *out = c->timing;
+  return TALC_OK;
+}
+
+// ------------------------------------------------------------------ batch
+void talc_batch_destroy(talc_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  void* ptrs[] = {b->d_raw, b->d_codes, b->d_offsets, b->d_koff, b->d_tile_read, b->d_tile_start, b->d_chunk_read,
+                  b->d_chunk_start, b->d_order, b->d_cov, b->d_nin, b->d_state, b->d_regions, b->d_regoff, b->d_out, b->d_outoff,
+                  b->d_dense, b->d_dense_off};
+  for (void* p : ptrs) if (p) hipFree(p);
+  delete b;
+}
+
+int talc_batch_create(talc_ctx* c, const char* bases, const uint64_t* offsets, uint32_t n_reads, talc_batch** out) {
+  if (!c || !offsets || !out || (!bases && n_reads && offsets[n_reads] > 0)) return fail(TALC_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  talc_batch* b = new talc_batch();
+  b->ctx = c; b->n_reads = n_reads;
+  b->h_offsets.assign(offsets, offsets + n_reads + 1);
+  if (b->h_offsets[0] != 0) { delete b; return fail(TALC_ERR_INVALID, "offsets[0] must be 0"); }
+  b->n_bases = b->h_offsets[n_reads];
+  const uint32_t K = c->p.k;
+  b->h_koff.resize(n_reads + 1);
+  b->h_regoff.resize(n_reads + 1);
+  b->h_outoff.resize(n_reads + 1);
+  uint64_t ko = 0, ro = 0, oo = 0;
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    if (offsets[r + 1] < offsets[r]) { delete b; return fail(TALC_ERR_INVALID, "offsets must be non-decreasing"); }
+    const uint64_t L = offsets[r + 1] - offsets[r];
+    if (L > 0x7fffff00ull) { delete b; return fail(TALC_ERR_INVALID, "read %u too long", r); }
+    b->max_len = std::max<uint32_t>(b->max_len, (uint32_t)L);
+    const uint64_t nk = L >= K ? L - K + 1 : 0;
+    b->h_koff[r] = ko; ko += nk;
+    b->h_regoff[r] = ro; ro += nk / 2 + 2;
+    b->h_outoff[r] = oo; oo += out_capacity_for(L);
+    for (uint64_t p = 0; p < nk; p += COV_TILE) { b->h_tile_read.push_back(r); b->h_tile_start.push_back((uint32_t)p); }
+    for (uint64_t p = 0; p < L; p += 4096) { b->h_chunk_read.push_back(r); b->h_chunk_start.push_back((uint32_t)p); }
+  }
+  b->h_koff[n_reads] = ko; b->h_regoff[n_reads] = ro; b->h_outoff[n_reads] = oo;
+  b->n_kmers = ko; b->out_capacity = oo;
+  // longest reads first: the path-search queue is consumed in this order
+  b->h_order.resize(n_reads);
+  std::iota(b->h_order.begin(), b->h_order.end(), 0u);
+  std::stable_sort(b->h_order.begin(), b->h_order.end(), [&](uint32_t x, uint32_t y) {
+    return (offsets[x + 1] - offsets[x]) > (offsets[y + 1] - offsets[y]);
+  });
+  hipStream_t s = c->stream;
+  int rc;
+  HIPCHK(hipMalloc((void**)&b->d_raw, std::max<uint64_t>(b->n_bases, 1)));
+  HIPCHK(hipMalloc((void**)&b->d_codes, std::max<uint64_t>(b->n_bases, 1)));
+  if (b->n_bases) HIPCHK(hipMemcpyAsync(b->d_raw, bases, b->n_bases, hipMemcpyHostToDevice, s));
+  if ((rc = up(&b->d_offsets, b->h_offsets, s))) return rc;
+  if ((rc = up(&b->d_koff, b->h_koff, s))) return rc;
+  if ((rc = up(&b->d_regoff, b->h_regoff, s))) return rc;
+  if ((rc = up(&b->d_outoff, b->h_outoff, s))) return rc;
+  if ((rc = up(&b->d_tile_read, b->h_tile_read, s))) return rc;
+  if ((rc = up(&b->d_tile_start, b->h_tile_start, s))) return rc;
+  if ((rc = up(&b->d_chunk_read, b->h_chunk_read, s))) return rc;
+  if ((rc = up(&b->d_chunk_start, b->h_chunk_start, s))) return rc;
+  if ((rc = up(&b->d_order, b->h_order, s))) return rc;
+  HIPCHK(hipMalloc((void**)&b->d_cov, std::max<uint64_t>(b->n_kmers, 1) * sizeof(uint2)));
+  HIPCHK(hipMalloc((void**)&b->d_nin, std::max<uint32_t>(n_reads, 1) * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_state, std::max<uint32_t>(n_reads, 1) * sizeof(ReadState)));
+  HIPCHK(hipMalloc((void**)&b->d_regions, std::max<uint64_t>(ro, 1) * 2 * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&b->d_out, std::max<uint64_t>(oo, 1)));
+  HIPCHK(hipStreamSynchronize(s));
+  *out = b;
+  return TALC_OK;
+}
+
+uint64_t talc_batch_num_kmers(const talc_batch* b) { return b ? b->n_kmers : 0; }
+uint64_t talc_batch_num_bases(const talc_batch* b) { return b ? b->n_bases : 0; }
+
+static int launch_encode(talc_ctx* c, talc_batch* b) {
+  if (!b->h_chunk_read.empty())
+    hipLaunchKernelGGL(k_encode, dim3((unsigned)b->h_chunk_read.size()), dim3(256), 0, c->stream, b->d_raw, b->d_codes,
+                       b->d_offsets, b->d_chunk_read, b->d_chunk_start, c->p.reverse ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  b->encoded = true;
+  return TALC_OK;
+}
+static int launch_coverage(talc_ctx* c, talc_batch* b) {
+  HIPCHK(hipMemsetAsync(b->d_nin, 0, std::max<uint32_t>(b->n_reads, 1) * sizeof(int32_t), c->stream));
+  if (!b->h_tile_read.empty())
+    hipLaunchKernelGGL(k_coverage, dim3((unsigned)b->h_tile_read.size()), dim3(COV_THREADS), 0, c->stream, c->view,
+                       b->d_codes, b->d_offsets, b->d_koff, b->d_tile_read, b->d_tile_start, b->d_cov, b->d_nin,
+                       c->p.min_count);
+  HIPCHK(hipGetLastError());
+  b->covered = true;
+  return TALC_OK;
+}
+
+int talc_batch_coverage(talc_ctx* c, talc_batch* b) {
+  if (!c || !b || b->ctx != c) return fail(TALC_ERR_INVALID, "bad context/batch");
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  HIPCHK(hipEventRecord(c->ev[0], c->stream));
+  if (!b->encoded && (rc = launch_encode(c, b))) return rc;
+  HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  if ((rc = launch_coverage(c, b))) return rc;
+  HIPCHK(hipEventRecord(c->ev[2], c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipEventElapsedTime(&c->timing.encode_ms, c->ev[0], c->ev[1]));
+  HIPCHK(hipEventElapsedTime(&c->timing.coverage_ms, c->ev[1], c->ev[2]));
+  c->timing.n_kmers = b->n_kmers; c->timing.n_bases = b->n_bases;
+  return TALC_OK;
+}
+
+int talc_batch_fetch_coverage(talc_ctx* c, talc_batch* b, uint32_t* counts, uint32_t* jcounts, uint64_t* kmer_offsets,
+                              int32_t* n_in_kmers) {
+  if (!c || !b || b->ctx != c) return fail(TALC_ERR_INVALID, "bad context/batch");
+  if (!b->covered) return fail(TALC_ERR_STATE, "coverage has not been computed for this batch");
+  HIPCHK(hipSetDevice(c->device));
+  if (b->n_kmers && (counts || jcounts)) {
+    std::vector<uint2> h(b->n_kmers);
+    HIPCHK(hipMemcpy(h.data(), b->d_cov, b->n_kmers * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < b->n_kmers; ++i) { if (counts) counts[i] = h[i].x; if (jcounts) jcounts[i] = h[i].y; }
+  }
+  if (kmer_offsets) memcpy(kmer_offsets, b->h_koff.data(), (b->n_reads + 1) * 8);
+  if (n_in_kmers && b->n_reads) HIPCHK(hipMemcpy(n_in_kmers, b->d_nin, b->n_reads * 4, hipMemcpyDeviceToHost));
+  return TALC_OK;
+}
+
+#include "talc_capi_correct.inc"
+
+}  // extern "C"

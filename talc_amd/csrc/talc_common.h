@@ -1,0 +1,85 @@
+// talc_common.h — types shared by the host side and the HIP kernels of libtalc_hip.so.
+#pragma once
+#include <stdint.h>
+
+#include "talc_hip.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TALC_HD __host__ __device__ __forceinline__
+#define TALC_D __device__ __forceinline__
+#else
+#define TALC_HD inline
+#define TALC_D inline
+#endif
+
+namespace talc {
+
+// ------------------------------------------------------------------ successor-grouped k-mer table
+// The reference's std::map<Dna5String, pair<uint,uint>> (Jellyfish.hpp:32-34) becomes two
+// open-addressed tables of 32-byte buckets, one per walking direction:
+//   RIGHT table: key = the (K-1)-prefix p of a k-mer;  cnt[b] / jc[b] = values of k-mer p+b
+//   LEFT  table: key = the (K-1)-suffix s of a k-mer;  cnt[b] / jc[b] = values of k-mer b+s
+// so the four successors of a Trail tip (getNextCounts, Jellyfish.cpp:308-321) are ONE aligned
+// 32-byte HBM access instead of four random ones, and a point lookup (getCount) is one access
+// to the RIGHT table.  cnt[b]==0 means "absent" (stored counts are >= min_count >= 1).
+// Junction colours are < coloured_count_thr <= 65535 (Jellyfish.cpp:64,284), hence 16 bits.
+struct __attribute__((aligned(32))) Bucket {
+  uint64_t key;      // packed (K-1)-mer; kEmptyKey if unused
+  uint32_t cnt[4];
+  uint16_t jc[4];
+};
+static_assert(sizeof(Bucket) == 32, "bucket must be 32 bytes");
+
+static const uint64_t kEmptyKey = ~0ULL;
+
+struct TableView {
+  const Bucket* right;   // device (or host) pointer
+  const Bucket* left;
+  uint64_t capacity;     // buckets per table (any size; home = mulhi(mix64(key), capacity))
+  uint32_t k;
+};
+
+TALC_HD uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// ------------------------------------------------------------------ Dna5 codes
+// reads live in HBM as one byte per base: A=0 C=1 G=2 T=3 N=4 (SeqAn Dna5 ordinals)
+enum : uint8_t { BASE_A = 0, BASE_C = 1, BASE_G = 2, BASE_T = 3, BASE_N = 4 };
+
+TALC_HD uint8_t ascii_to_code(uint8_t c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+TALC_HD uint8_t complement_code(uint8_t c) { return c < 4 ? (uint8_t)(3 - c) : (uint8_t)4; }
+TALC_HD char code_to_ascii(uint8_t c) { return c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : c == 3 ? 'T' : 'N'; }
+
+// Device copy of the parameters (talc_params + derived values)
+struct DevParams {
+  uint32_t K;
+  uint32_t MIN_COUNT;
+  double ALPHA;
+  uint32_t WINDOW;
+  double ERR;
+  double MIN_INNER;
+  double MIN_BORDER;
+  uint32_t MAXB;
+  int32_t reverse;
+  uint32_t MIN_START_ANCHORS, MAX_START_ANCHORS, MAX_IN_COUNT, MAX_BORDER_PATHS, MAX_INNER_PATHS, CHECK_INTERVAL;
+  double FAILURE_RATE;
+  int32_t MAX_BORDER_FAILURES;
+  uint32_t MAX_BORDER_LEN;
+};
+
+}  // namespace talc

@@ -1,0 +1,179 @@
+// talc_kernels_probe.h — device-side table probes and the k-mer coverage kernel
+// (replaces getCountFromDBG / getNextCountsFromDBG / getLRCountsInSRFromDBG,
+//  Jellyfish.cpp:407-413, 308-321, 485-496, and Read::reCoverage, Read.cpp:174-195).
+#pragma once
+#include "talc_common.h"
+
+namespace talc {
+
+TALC_D uint64_t dev_home(uint64_t key, uint64_t cap) { return __umul64hi(mix64(key), cap); }
+
+// One bucket = two 16-byte loads from the same 32-byte sector.
+struct BucketRegs {
+  uint64_t key;
+  uint32_t cnt[4];
+  uint32_t jc01, jc23;  // packed u16 pairs
+  TALC_D uint32_t jc(int b) const { uint32_t w = (b < 2) ? jc01 : jc23; return (b & 1) ? (w >> 16) : (w & 0xffffu); }
+};
+
+TALC_D BucketRegs load_bucket(const Bucket* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  BucketRegs r;
+  r.key = ((uint64_t)a.y << 32) | a.x;
+  r.cnt[0] = a.z; r.cnt[1] = a.w; r.cnt[2] = b.x; r.cnt[3] = b.y;
+  r.jc01 = b.z; r.jc23 = b.w;
+  return r;
+}
+
+// Linear probing; returns true and fills `out` when the (K-1)-mer key is present.
+TALC_D bool probe_bucket(const Bucket* tab, uint64_t cap, uint64_t key, BucketRegs& out) {
+  uint64_t i = dev_home(key, cap);
+  while (true) {
+    BucketRegs r = load_bucket(tab + i);
+    if (r.key == key) { out = r; return true; }
+    if (r.key == kEmptyKey) return false;
+    if (++i == cap) i = 0;
+  }
+}
+
+// getCount (Jellyfish.cpp:407-413) for a packed K-mer
+TALC_D void dev_get_count(const TableView& T, uint64_t kmer, uint32_t& cnt, uint32_t& jc) {
+  BucketRegs r;
+  cnt = 0; jc = 0;
+  if (probe_bucket(T.right, T.capacity, kmer >> 2, r)) { const int b = (int)(kmer & 3); cnt = r.cnt[b]; jc = r.jc(b); }
+}
+
+// getNextCounts (Jellyfish.cpp:308-321): the 4 successors of `kmer` walking RIGHT
+// (drop first base, append b) or LEFT (prepend b, drop last), order A,C,G,T.
+TALC_D void dev_next_counts(const TableView& T, uint64_t kmer, int dirRight, uint32_t cnt[4], uint32_t jc[4]) {
+  const uint64_t m1 = (1ULL << (2 * (T.k - 1))) - 1;
+  BucketRegs r;
+  bool ok;
+  if (dirRight) ok = probe_bucket(T.right, T.capacity, kmer & m1, r);
+  else ok = probe_bucket(T.left, T.capacity, kmer >> 2, r);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { cnt[b] = ok ? r.cnt[b] : 0u; jc[b] = ok ? r.jc(b) : 0u; }
+}
+
+// ------------------------------------------------------------------ test-hook kernels
+__global__ void k_lookup(TableView T, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* jcounts) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c, j;
+  dev_get_count(T, kmers[i], c, j);
+  counts[i] = c; jcounts[i] = j;
+}
+__global__ void k_next_counts(TableView T, const uint64_t* kmers, uint64_t n, int dirRight, uint32_t* counts4,
+                              uint32_t* jcounts4) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c[4], j[4];
+  dev_next_counts(T, kmers[i], dirRight, c, j);
+  for (int b = 0; b < 4; ++b) { counts4[4 * i + b] = c[b]; jcounts4[4 * i + b] = j[b]; }
+}
+
+// ------------------------------------------------------------------ encode
+// raw ASCII -> Dna5 codes (SeqAn Dna5 conversion), with the -rev reverse complement of
+// main.cpp:253 applied per read.  One block per (read, 4096-base chunk).
+__global__ void k_encode(const uint8_t* __restrict__ raw, uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
+                         const uint32_t* __restrict__ chunk_read, const uint32_t* __restrict__ chunk_start, int reverse) {
+  const uint32_t r = chunk_read[blockIdx.x];
+  const uint64_t b = offsets[r], e = offsets[r + 1];
+  const uint64_t L = e - b;
+  const uint64_t s0 = chunk_start[blockIdx.x];
+  for (uint64_t i = s0 + threadIdx.x; i < s0 + 4096 && i < L; i += blockDim.x) {
+    uint8_t c = ascii_to_code(raw[b + i]);
+    if (reverse) codes[b + (L - 1 - i)] = complement_code(c);
+    else codes[b + i] = c;
+  }
+}
+
+// ------------------------------------------------------------------ coverage (the k-mer probe kernel)
+// One block per tile of up to COV_TILE consecutive k-mer positions of ONE read.
+//  1. the tile's base window (COV_TILE + K - 1 codes) is staged into LDS as 2-bit packed words
+//     plus an N bitmap (coalesced byte loads, 8 bases per thread per pass);
+//  2. thread t takes positions t, t+256, ... : the k-mer is two LDS words funnel-shifted;
+//     its (K-1)-prefix is hashed and the 32-byte bucket probed in HBM (the only random access);
+//  3. (count, colour) is written as one 8-byte store per k-mer, coalesced across the wave;
+//  4. #{count > MIN_COUNT} (Read.cpp:190) is reduced per block and added to the read's counter.
+#define COV_TILE 2048
+#define COV_THREADS 256
+
+__global__ void __launch_bounds__(COV_THREADS)
+k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
+           const uint64_t* __restrict__ koff, const uint32_t* __restrict__ tile_read,
+           const uint32_t* __restrict__ tile_start, uint2* __restrict__ cov, int32_t* __restrict__ n_in,
+           uint32_t min_count) {
+  __shared__ uint64_t s_pack[(COV_TILE + 64) / 32 + 2];
+  __shared__ uint64_t s_nmask[(COV_TILE + 64) / 64 + 2];
+  __shared__ int s_nin;
+  const uint32_t K = T.k;
+  const uint32_t r = tile_read[blockIdx.x];
+  const uint32_t p0 = tile_start[blockIdx.x];
+  const uint64_t rb = offsets[r];
+  const uint32_t L = (uint32_t)(offsets[r + 1] - rb);
+  const uint32_t nk = L - K + 1;                       // k-mers in this read (host guarantees L >= K)
+  const uint32_t cnt = min((uint32_t)COV_TILE, nk - p0);  // positions in this tile
+  const uint32_t wlen = cnt + K - 1;                  // bases in the window
+  const uint8_t* src = codes + rb + p0;
+
+  if (threadIdx.x == 0) s_nin = 0;
+  // stage: 16 bases -> one u32 of 2-bit codes + 16 N bits, per thread per pass
+  {
+    uint32_t* pk32 = reinterpret_cast<uint32_t*>(s_pack);
+    uint16_t* nm16 = reinterpret_cast<uint16_t*>(s_nmask);
+    const uint32_t ngroups = (wlen + 15) / 16;
+    for (uint32_t g = threadIdx.x; g < ngroups; g += COV_THREADS) {
+      uint32_t w = 0, nm = 0;
+      const uint32_t base = g * 16;
+#pragma unroll
+      for (uint32_t j = 0; j < 16; ++j) {
+        uint32_t c = (base + j < wlen) ? (uint32_t)src[base + j] : 0u;
+        nm |= (c > 3u ? 1u : 0u) << j;
+        w |= (c & 3u) << (2 * j);   // base j of the group at bits [2j, 2j+1]: little-endian within the word
+      }
+      pk32[g] = w;
+      nm16[g] = (uint16_t)nm;
+    }
+    // zero one guard word so the funnel shift below never reads uninitialised LDS
+    if (threadIdx.x == 0) { pk32[ngroups] = 0; pk32[ngroups + 1] = 0; nm16[ngroups] = 0; nm16[ngroups + 1] = 0;
+                            nm16[ngroups + 2] = 0; nm16[ngroups + 3] = 0; }
+  }
+  __syncthreads();
+
+  const uint64_t kbits = 2ull * K;
+  const uint64_t kmaskLE = (K >= 32) ? ~0ULL : ((1ULL << kbits) - 1);
+  int local_in = 0;
+  uint2* out = cov + koff[r] + p0;
+  for (uint32_t p = threadIdx.x; p < cnt; p += COV_THREADS) {
+    // little-endian packed window: base i at bits [2i,2i+1] of the bit stream
+    const uint32_t bit = 2 * p;
+    const uint32_t w = bit >> 6, sh = bit & 63;
+    uint64_t lo = s_pack[w], hi = s_pack[w + 1];
+    uint64_t le = (sh == 0) ? lo : ((lo >> sh) | (hi << (64 - sh)));
+    le &= kmaskLE;  // base p+i at bits [2i, 2i+1]
+    // N test: any N among bases [p, p+K)
+    const uint32_t nw = p >> 6, nsh = p & 63;
+    uint64_t nlo = s_nmask[nw], nhi = s_nmask[nw + 1];
+    uint64_t nb = (nsh == 0) ? nlo : ((nlo >> nsh) | (nhi << (64 - nsh)));
+    nb &= (K >= 64) ? ~0ULL : ((1ULL << K) - 1);
+    // convert to the table's big-endian packing (first base most significant): reverse 2-bit groups
+    uint64_t x = le;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);
+    const uint64_t kmer = x >> (64 - kbits);
+    uint32_t c = 0, j = 0;
+    if (nb == 0) dev_get_count(T, kmer, c, j);
+    out[p] = make_uint2(c, j);
+    local_in += (c > min_count) ? 1 : 0;
+  }
+  // block reduction of local_in
+  for (int off = 32; off > 0; off >>= 1) local_in += __shfl_down(local_in, off, 64);
+  if ((threadIdx.x & 63) == 0 && local_in) atomicAdd(&s_nin, local_in);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_nin) atomicAdd(&n_in[r], s_nin);
+}
+
+}  // namespace talc

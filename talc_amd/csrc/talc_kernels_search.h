@@ -1,0 +1,1315 @@
+// talc_kernels_search.h — structure + path-search + reassembly kernels.
+//
+// Device restatement of the reference's per-read correction:
+//   k_structure : Read::defineStructure2           Read.cpp:260-276, 440-600, 214-258
+//   k_search    : Read::correct2                   Read.cpp:336-386
+//                 Explorer::searchBridge/searchEdge Explorer.cpp:868-1081 and everything below them
+//                 (anchors :413-543, oneMoreStep :546-612, oneMoreStepInTheDark :615-687,
+//                  scoreBridges :689-706, scoreEdges :709-740, gardening :773-865, Trail.cpp,
+//                  Trajectory.cpp)
+//   k_pack      : Read::updateCorrSeq / getCorrSeq + the -rev undo of main.cpp:286
+//
+// One wavefront per read (see talc_wave.h).  Candidate paths ("Trails") are flat byte strings
+// in growth order in per-wave HBM scratch, in two ping-pong sets of TCAP slots.
+#pragma once
+#include "talc_common.h"
+#include "talc_kernels_probe.h"
+#include "talc_pure.h"
+#include "talc_wave.h"
+
+namespace talc {
+
+#define TCAP 288          /* slots per Trail set: <= 4*max_inner_paths children, or kept + MAXB */
+#define LDS_DP_CAP 1280   /* ints per DP array held in LDS; longer problems use the HBM arrays */
+
+enum : uint32_t {
+  OVF_ANCHORS = 1, OVF_FULLPATHS = 2, OVF_FULLPOOL = 4, OVF_TRAILS = 8, OVF_SEQ = 16, OVF_OUT = 32, OVF_WEAKPOOL = 64,
+  OVF_REGIONS = 128, OVF_DP = 256
+};
+
+struct ReadState {
+  int32_t status;       // talc_read_status (TALC_READ_CORRECTED == structure defined, to be searched)
+  uint32_t nRegions;
+  double lambda;        // m_priorLambda_noise (Read.cpp:268-269)
+  uint32_t outLen;      // corrected length in codes (growth of the read's out slot)
+  uint32_t overflow;    // OVF_* bits: scratch exhausted, read left unchanged
+};
+
+__host__ __device__ inline uint64_t out_capacity_for(uint64_t L) { return 4 * L + 1024; }
+
+struct FullMeta { uint32_t off, len; int32_t lanc, ranc; double dist; };
+
+// per-wave scratch layout (byte offsets inside one slot)
+struct SearchCaps {
+  uint32_t seqCap;      // bytes per Trail sequence
+  uint32_t refCap;      // bytes of currentRefSeq
+  uint32_t edgeCap;     // bytes per edge candidate sequence
+  uint32_t anchCap;     // anchors per side
+  uint32_t fullCap;     // recorded bridges per start anchor
+  uint32_t fullPool;    // bytes for their sequences
+  uint32_t dpCap;       // ints per HBM DP array
+  uint32_t regCap;      // regions per read
+  uint32_t weakPool;    // bytes for corrected weak sequences
+  uint64_t slotBytes;
+  uint64_t o_setA, o_setB, o_seqA, o_seqB, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
+      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak;
+};
+
+static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// metadata of one Trail set: SoA, TCAP entries each
+struct TrailSetLayout {
+  static constexpr uint64_t kmer = 0;
+  static constexpr uint64_t nmask = kmer + 8ull * TCAP;
+  static constexpr uint64_t dist = nmask + 8ull * TCAP;
+  static constexpr uint64_t cnt = dist + 8ull * TCAP;
+  static constexpr uint64_t score = cnt + 4ull * TCAP;
+  static constexpr uint64_t fail = score + 4ull * TCAP;
+  static constexpr uint64_t lanc = fail + 4ull * TCAP;
+  static constexpr uint64_t ranc = lanc + 4ull * TCAP;
+  static constexpr uint64_t bytes = ranc + 4ull * TCAP;
+};
+
+static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale) {
+  SearchCaps c;
+  memset(&c, 0, sizeof c);
+  const uint64_t Lm = maxLen;
+  c.seqCap = (uint32_t)align_up((uint64_t)(1.2 * (double)Lm) + 4ull * K + 64, 16);
+  c.refCap = (uint32_t)align_up(Lm + 2ull * K + 64, 16);
+  c.edgeCap = (uint32_t)align_up((uint64_t)c.seqCap + c.refCap, 16);
+  c.anchCap = 256 * scale;
+  c.fullCap = 128 * scale;
+  c.fullPool = (uint32_t)align_up((uint64_t)c.seqCap * 16 * scale, 16);
+  c.dpCap = (uint32_t)align_up(std::max<uint64_t>(c.edgeCap, c.seqCap) + 8, 4);
+  c.regCap = (uint32_t)(Lm / 2 + 4);
+  c.weakPool = (uint32_t)align_up(out_capacity_for(Lm), 16);
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) { uint64_t r = o; o = align_up(o + bytes, 16); return r; };
+  c.o_setA = take(TrailSetLayout::bytes);
+  c.o_setB = take(TrailSetLayout::bytes);
+  c.o_seqA = take((uint64_t)TCAP * c.seqCap);
+  c.o_seqB = take((uint64_t)TCAP * c.seqCap);
+  c.o_ref = take(c.refCap);
+  c.o_ancL = take((uint64_t)c.anchCap * sizeof(AnchorRec));
+  c.o_ancR = take((uint64_t)c.anchCap * sizeof(AnchorRec));
+  c.o_ancPos = take((uint64_t)c.anchCap * 4);
+  c.o_fullMeta = take((uint64_t)c.fullCap * sizeof(FullMeta));
+  c.o_fullPoolB = take(c.fullPool);
+  c.o_edgeLong = take(c.edgeCap);
+  c.o_edgeShort = take(c.edgeCap);
+  c.o_edgeTmp = take(c.edgeCap);
+  c.o_dp = take(3ull * c.dpCap * 4);
+  c.o_gard = take((uint64_t)(TCAP + 64) * (8 + 8 + 16 + 32 + 4));
+  c.o_regS = take((uint64_t)c.regCap * 4);
+  c.o_regE = take((uint64_t)c.regCap * 4);
+  c.o_wOff = take((uint64_t)c.regCap * 4);
+  c.o_wLen = take((uint64_t)c.regCap * 4);
+  c.o_weak = take(c.weakPool);
+  c.slotBytes = align_up(o, 256);
+  return c;
+}
+
+#if defined(__HIPCC__)
+
+// ------------------------------------------------------------------ trace (debug hook)
+struct TraceRec { int32_t kind; int32_t a, b, c, d; double x; uint32_t soff, slen; };
+struct TraceBuf { TraceRec* recs; uint32_t* nrec; uint32_t cap; uint8_t* pool; uint32_t* npool; uint32_t poolCap; int steps; };
+enum { TR_REGION = 1, TR_THRESHOLD = 2, TR_SEARCH = 3, TR_ANCHOR = 4, TR_RESULT = 5, TR_STEP = 6 };
+
+// ------------------------------------------------------------------ small wave helpers on reads
+// packed natural-orientation k-mer (+ N mask) of s[0..K): lanes 0..K-1 load one base each
+TALC_D void wave_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, uint64_t& nmask) {
+  const int l = lane_id();
+  uint32_t c = (l < K) ? (uint32_t)s[l] : 0u;
+  nmask = ballot64((l < K) && (c > 3u));
+  uint64_t v = (l < K) ? ((uint64_t)(c & 3u) << (2 * (K - 1 - l))) : 0ull;
+  if (c > 3u) v = 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo |= (uint32_t)__shfl_xor((int)lo, off, 64);
+    hi |= (uint32_t)__shfl_xor((int)hi, off, 64);
+    v = ((uint64_t)hi << 32) | lo;
+  }
+  kmer = v;
+}
+
+// getOutDegree (Jellyfish.cpp:383-393) of a packed k-mer: uniform call, one bucket probe
+TALC_D int dev_out_degree(const TableView& T, uint32_t MINC, uint64_t kmer, uint64_t nmask, int dirRight) {
+  const uint32_t K = T.k;
+  const uint64_t succN = dirRight ? (nmask >> 1) : (nmask & ((1ULL << (K - 1)) - 1));
+  if (succN) return 0;  // every successor contains an N: absent from the table
+  uint32_t c[4], j[4];
+  dev_next_counts(T, kmer, dirRight, c, j);
+  int d = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) d += (c[b] >= MINC) ? 1 : 0;
+  return d;
+}
+
+// ==================================================================== k_structure
+// Read::defineStructure2 for one read per wave.
+// S(r) = sum of the r smallest IN counts, by binary search on the value (order statistics
+// without sorting: the reference's sort only feeds a trimmed sum, Read.cpp:505-512).
+TALC_D unsigned long long trimmed_prefix_sum(const uint2* __restrict__ cov, uint32_t n, uint32_t MINC, uint32_t r) {
+  if (r == 0) return 0ull;
+  const int l = lane_id();
+  // smallest v with #{x >= MINC, x <= v} >= r
+  uint32_t lo = 0, hi = 0xFFFFFFFFu;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    unsigned long long cnt = 0;
+    for (uint32_t i = l; i < n; i += 64) { const uint32_t x = cov[i].x; cnt += (x >= MINC && x <= mid) ? 1 : 0; }
+    cnt = wave_sum_u64(cnt);
+    if (cnt >= r) hi = mid; else lo = mid + 1;
+  }
+  const uint32_t v = lo;
+  unsigned long long sumLess = 0, cntLess = 0;
+  for (uint32_t i = l; i < n; i += 64) {
+    const uint32_t x = cov[i].x;
+    if (x >= MINC && x < v) { sumLess += x; cntLess += 1; }
+  }
+  sumLess = wave_sum_u64(sumLess);
+  cntLess = wave_sum_u64(cntLess);
+  return sumLess + ((unsigned long long)r - cntLess) * (unsigned long long)v;
+}
+
+__global__ void __launch_bounds__(64)
+k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
+            const uint64_t* __restrict__ koff, const uint2* __restrict__ covAll, const int32_t* __restrict__ n_in,
+            ReadState* __restrict__ state, uint32_t* __restrict__ regions, const uint64_t* __restrict__ regoff,
+            uint32_t n_reads, TraceBuf trace, uint32_t traceRead) {
+  const uint32_t r = blockIdx.x;
+  if (r >= n_reads) return;
+  const int l = lane_id();
+  const uint32_t K = P.K, MINC = P.MIN_COUNT;
+  const uint8_t* read = codes + offsets[r];
+  const uint32_t L = (uint32_t)(offsets[r + 1] - offsets[r]);
+  ReadState st;
+  st.status = TALC_READ_CORRECTED; st.nRegions = 0; st.lambda = (double)MINC; st.outLen = 0; st.overflow = 0;
+  if (!(L > K)) { st.status = TALC_READ_SKIPPED_SHORT; if (l == 0) state[r] = st; return; }      // main.cpp:262
+  if (!(n_in[r] > 0)) { st.status = TALC_READ_NO_SOLID_KMER; if (l == 0) state[r] = st; return; }  // Read.cpp:194
+  const uint32_t n = L - K + 1;
+  const uint2* cov = covAll + koff[r];
+  uint32_t* regS = regions + 2 * regoff[r];
+  const uint32_t regCap = (uint32_t)(regoff[r + 1] - regoff[r]);
+  uint32_t* regE = regS + regCap;
+
+  // ---- findINRegions (Read.cpp:440-489): maximal runs of count >= MIN_COUNT (needs n > 1)
+  uint32_t R = 0, Rends = 0;
+  if (n > 1) {
+    for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t i = base + l;
+      const bool in = (i < n) && (cov[i].x >= MINC);
+      const bool inPrev = (i > 0) && (i < n) && (cov[i - 1].x >= MINC);
+      const bool inNext = (i + 1 < n) && (cov[i + 1].x >= MINC);
+      const bool isStart = in && !inPrev, isEnd = in && !inNext;
+      const unsigned long long ms = ballot64(isStart), me = ballot64(isEnd);
+      // the k-th start pairs with the k-th end
+      const unsigned long long below = (l == 0) ? 0ull : (~0ull >> (64 - l));
+      if (isStart) { const uint32_t k = R + (uint32_t)__popcll(ms & below); if (k < regCap) regS[k] = i; }
+      if (isEnd) { const uint32_t k = Rends + (uint32_t)__popcll(me & below); if (k < regCap) regE[k] = i; }
+      R += (uint32_t)__popcll(ms);
+      Rends += (uint32_t)__popcll(me);
+    }
+  }
+  if (R > regCap) { st.overflow |= OVF_REGIONS; R = regCap; }
+  WSYNC();
+
+  // ---- computeSeqErrorThreshold (Read.cpp:493-518)
+  unsigned long long m = 0;
+  for (uint32_t i = l; i < n; i += 64) m += (cov[i].x >= MINC) ? 1 : 0;
+  m = wave_sum_u64(m);
+  uint32_t first = 0, last = (uint32_t)m;
+  if (m > 10) { first = (uint32_t)(0.15 * (double)m); last = (uint32_t)(0.90 * (double)m); }
+  const unsigned long long sum = trimmed_prefix_sum(cov, n, MINC, last) - trimmed_prefix_sum(cov, n, MINC, first);
+  double robMean = (double)((unsigned long long)MINC + sum);
+  robMean /= (double)(last - first);
+  const double thr = robMean * P.ERR;
+  st.lambda = thr;
+
+  // ---- analyzeINRegions (Read.cpp:524-600): uniform serial walk over the regions
+  // new list is written in place behind a write cursor (nNew <= reg always)
+  uint32_t nNew = 0;
+  {
+    const uint32_t solidThr = (uint32_t)thr;
+    for (uint32_t reg = 0; reg < R; ++reg) {
+      int span = 0;
+      bool OK = true;
+      uint32_t new_start_pos = regS[reg];
+      const uint32_t regEnd = regE[reg];
+      uint64_t km, nm;
+      const bool lastAndNone = ((R == reg + 1) & (nNew == 0));
+      wave_kmer_at(read + new_start_pos, (int)K, km, nm);
+      if (!lastAndNone & (dev_out_degree(T, MINC, km, nm, 0) == 0) & (new_start_pos != 0)) {
+        OK = false;
+        while ((new_start_pos < regEnd) & !OK) {
+          ++new_start_pos;
+          wave_kmer_at(read + new_start_pos, (int)K, km, nm);
+          if (dev_out_degree(T, MINC, km, nm, 0) > 1) OK = true;
+        }
+      }
+      uint32_t new_end_pos = regEnd;
+      if (OK & !lastAndNone) {
+        wave_kmer_at(read + new_end_pos, (int)K, km, nm);
+        if ((dev_out_degree(T, MINC, km, nm, 1) == 0) & (new_end_pos != n - 1)) {
+          OK = false;
+          while ((new_end_pos > regS[reg]) & !OK) {
+            --new_end_pos;
+            wave_kmer_at(read + new_end_pos, (int)K, km, nm);
+            if (dev_out_degree(T, MINC, km, nm, 1) > 1) OK = true;
+          }
+        }
+      }
+      if (OK) {
+        if (reg + 1 < R) span = ((int)regS[reg + 1] - (int)(new_end_pos + K));
+        if (span < 0) {
+          if ((int)regE[reg + 1] + span >= (int)regS[reg + 1]) { if (l == 0) regS[reg + 1] = regS[reg + 1] - (uint32_t)span; }
+          else { if (l == 0) regS[reg + 1] = new_start_pos; OK = false; }
+          WSYNC();
+        }
+        if (OK) {
+          uint32_t c = 0;
+          for (uint32_t i = new_start_pos + l; i <= new_end_pos; i += 64) c = max(c, cov[i].x);
+          c = wave_max_u32(c);
+          const bool expected = !is_expected_by_model(P.ALPHA, c, solidThr, true);
+          if (expected) {
+            // kept regions are compacted to the front; slot nNew <= reg has already been consumed
+            WSYNC();
+            if (l == 0) { regS[nNew] = new_start_pos; regE[nNew] = new_end_pos; }
+            WSYNC();
+            ++nNew;
+          }
+        }
+      }
+    }
+  }
+  // Read.cpp:599: the original list is kept when nothing qualified.  The in-place compaction above
+  // destroys it only if nNew > 0, but the span fix-ups (:582,:585) already edited the original list
+  // in place in the reference too, so when nNew == 0 regS/regE hold exactly what the reference keeps.
+  uint32_t Rfinal = (nNew > 0) ? nNew : R;
+  bool checok = (R > 0);   // findINRegions' return value (Read.cpp:488)
+
+  // ---- setInitialStructure (Read.cpp:214-258): only its length check decides anything here
+  if (Rfinal > 0) {
+    unsigned long long len = 0;
+    if (regS[0] > 0) len += regS[0];
+    const uint32_t eLast = regE[Rfinal - 1];
+    if (eLast + 1 < n) len += (unsigned long long)L - ((unsigned long long)eLast + K);
+    unsigned long long part = 0;
+    for (uint32_t i = l; i + 1 < Rfinal; i += 64) {
+      part += (unsigned long long)regE[i] + K - regS[i];
+      if (regS[i + 1] > regE[i] + K) part += (unsigned long long)regS[i + 1] - ((unsigned long long)regE[i] + K);
+    }
+    len += wave_sum_u64(part);
+    len += (unsigned long long)eLast + K - regS[Rfinal - 1];
+    checok &= (len == (unsigned long long)L);
+  }
+  st.nRegions = Rfinal;
+  if (!checok) st.status = TALC_READ_NO_STRUCTURE;   // main.cpp:290
+  if (l == 0) state[r] = st;
+  if (trace.recs && r == traceRead && l == 0) {
+    uint32_t k = atomicAdd(trace.nrec, 1u);
+    if (k < trace.cap) trace.recs[k] = TraceRec{TR_THRESHOLD, 0, 0, 0, 0, thr, 0, 0};
+    for (uint32_t i = 0; i < Rfinal; ++i) {
+      k = atomicAdd(trace.nrec, 1u);
+      if (k < trace.cap) trace.recs[k] = TraceRec{TR_REGION, (int)regS[i], (int)regE[i], 0, 0, 0.0, 0, 0};
+    }
+  }
+}
+
+// ==================================================================== k_search
+struct TrailSet {
+  uint64_t* kmer; uint64_t* nmask; double* dist; uint32_t* cnt; int32_t* score; uint32_t* fail; int32_t* lanc;
+  int32_t* ranc; uint8_t* seq;
+};
+TALC_D TrailSet make_set(uint8_t* meta, uint8_t* seq) {
+  TrailSet s;
+  s.kmer = (uint64_t*)(meta + TrailSetLayout::kmer); s.nmask = (uint64_t*)(meta + TrailSetLayout::nmask);
+  s.dist = (double*)(meta + TrailSetLayout::dist); s.cnt = (uint32_t*)(meta + TrailSetLayout::cnt);
+  s.score = (int32_t*)(meta + TrailSetLayout::score); s.fail = (uint32_t*)(meta + TrailSetLayout::fail);
+  s.lanc = (int32_t*)(meta + TrailSetLayout::lanc); s.ranc = (int32_t*)(meta + TrailSetLayout::ranc);
+  s.seq = seq;
+  return s;
+}
+
+struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online (findBestBORDER is a fold)
+  bool have; double score; double dist; double idscore; uint32_t len; uint32_t lanc, ranc;
+};
+
+struct Wv {
+  // kernel constants
+  DevParams P; TableView T; SearchCaps C;
+  // read
+  const uint8_t* read; uint32_t L, n; const uint2* cov; double lambda;
+  // scratch
+  TrailSet A, B;
+  uint8_t *ref, *fullPool, *edgeLong, *edgeShort, *edgeTmp, *weak;
+  AnchorRec *ancL, *ancR; uint32_t* ancPos;
+  FullMeta* fullMeta;
+  int *dpG;   // 3 x dpCap ints in HBM
+  int *dpL;   // 3 x LDS_DP_CAP ints in LDS
+  double* gScores; double* gDists; ValIdx* gVal; Rank4* gRank; uint32_t* gKept;
+  uint32_t *regS, *regE, *wOff, *wLen;
+  // explorer state (Explorer.hpp:151-174)
+  int location, dirRight;          // HEAD/INNER/TAIL as 0/1/2
+  uint32_t Ls, Le, Rs, Re;         // m_LEFT_KMpositions / m_RIGHT_KMpositions
+  uint32_t weakLen;
+  bool complexRegion;
+  int nAncL, nAncR;
+  uint32_t refLen;
+  int nFull; uint32_t fullUsed;
+  EdgeCand bestLong, bestShort;
+  int nEdges;
+  // counters
+  unsigned long long cells, steps;
+  uint32_t overflow;
+  TraceBuf trace; bool tracing;
+};
+
+enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
+
+TALC_D int* dp_array(Wv& X, int which, int need) {
+  if (need <= LDS_DP_CAP) return X.dpL + which * LDS_DP_CAP;
+  if ((uint32_t)need > X.C.dpCap) { X.overflow |= OVF_DP; }
+  return X.dpG + (uint64_t)which * X.C.dpCap;
+}
+
+TALC_D int nw_score(Wv& X, const uint8_t* a, int la, const uint8_t* b, int lb, int match, int mismatch, int gap,
+                    bool freeBegin) {
+  // the longer sequence spans the lanes (the score is symmetric in its arguments)
+  if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
+  if ((uint32_t)(la + 1) > X.C.dpCap && la + 1 > LDS_DP_CAP) { X.overflow |= OVF_DP; return 0; }
+  int* row = dp_array(X, 0, la + 1);
+  return wave_nw(a, la, b, lb, match, mismatch, gap, freeBegin, row, &X.cells);
+}
+
+// ------------------------------------------------------------------ trace helpers
+TALC_D void trace_rec(Wv& X, int kind, int a, int b, int c, int d, double x, const uint8_t* s, uint32_t slen, bool rev) {
+  if (!X.tracing) return;
+  WSYNC();
+  if (lane_id() == 0) {
+    uint32_t k = atomicAdd(X.trace.nrec, 1u);
+    uint32_t off = 0;
+    if (slen) { off = atomicAdd(X.trace.npool, slen); }
+    if (k < X.trace.cap) {
+      if (slen && off + slen <= X.trace.poolCap) for (uint32_t i = 0; i < slen; ++i) X.trace.pool[off + i] = rev ? s[slen - 1 - i] : s[i];
+      else if (slen) slen = 0;
+      X.trace.recs[k] = TraceRec{kind, a, b, c, d, x, off, slen};
+    }
+  }
+  WSYNC();
+}
+
+// ------------------------------------------------------------------ anchors (Explorer.cpp:413-543)
+// side 0: anchorLEFTHandSide (walks the LEFT region leftwards from its end, degree towards RIGHT)
+// side 1: anchorRIGHTHandSide (walks the RIGHT region rightwards from its start, degree towards LEFT)
+TALC_D void build_anchors(Wv& X, int side) {
+  const DevParams& P = X.P;
+  const uint32_t K = P.K, MINC = P.MIN_COUNT;
+  const int l = lane_id();
+  AnchorRec* anc = side == 0 ? X.ancL : X.ancR;
+  uint32_t* anchorPos = X.ancPos;
+  const uint32_t cap = X.C.anchCap;
+  const uint32_t rs = side == 0 ? X.Ls : X.Rs, re = side == 0 ? X.Le : X.Re;
+  const uint32_t nbKmers = re - rs + 1;
+  const uint32_t pivot = side == 0 ? re : rs;
+  const uint32_t limit = side == 0 ? rs : re;
+  bool goFurther = true;
+  double current_count = (double)X.cov[pivot].x;
+  double next_count = 0;
+  uint32_t j = pivot;
+  uint32_t nPos = 0;
+  if (l == 0) anchorPos[0] = pivot;
+  nPos = 1;
+  if (side == 0) {
+    while (goFurther & (j >= limit + 1)) {
+      next_count = (double)X.cov[j - 1].x;
+      if ((next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) goFurther = is_expected_by_last_node(P.ALPHA, (uint32_t)next_count, (uint32_t)current_count);
+      else goFurther = false;
+      if (!goFurther & (current_count >= MINC) & (next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) {
+        if (nPos < cap) { if (l == 0) anchorPos[nPos] = j - 1; } else X.overflow |= OVF_ANCHORS;
+        if (nPos < cap) ++nPos;
+        goFurther = true;
+        current_count = next_count;
+      }
+      --j;
+    }
+  } else {
+    while (goFurther & ((j + 1) <= limit)) {
+      next_count = (double)X.cov[j + 1].x;
+      if ((next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) goFurther = is_expected_by_last_node(P.ALPHA, (uint32_t)next_count, (uint32_t)current_count);
+      else goFurther = false;
+      if (!goFurther & (current_count >= MINC) & (next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) {
+        if (nPos < cap) { if (l == 0) anchorPos[nPos] = j + 1; } else X.overflow |= OVF_ANCHORS;
+        if (nPos < cap) ++nPos;
+        goFurther = true;
+        current_count = next_count;
+      }
+      ++j;
+    }
+  }
+  WSYNC();
+  uint32_t nAnc = 0;
+  uint32_t firstAnchorPos = 0;
+  for (uint32_t a = 0; a < nPos; ++a) {
+    const uint32_t pos = anchorPos[a];
+    uint64_t km, nm;
+    wave_kmer_at(X.read + pos, (int)K, km, nm);
+    const int degree = dev_out_degree(X.T, MINC, km, nm, side == 0 ? 1 : 0);
+    if ((a == 0) || ((a != 0) & (degree > 1))) {
+      // Explorer.cpp:454,520: the recorded count is m_coverage[anc] (loop index), not [anchorPos[anc]]
+      if (nAnc < cap) {
+        if (l == 0) anc[nAnc] = AnchorRec{km, nm, pos, X.cov[a].x};
+        if (nAnc == 0) firstAnchorPos = pos;
+        ++nAnc;
+      } else X.overflow |= OVF_ANCHORS;
+    }
+  }
+  const uint32_t want = min(P.MIN_START_ANCHORS, nbKmers);
+  if (nAnc < want) {
+    j = pivot;
+    goFurther = true;
+    if (side == 0) {
+      while ((j >= limit + 1) & (nAnc < want)) {
+        // :465 `for(unsigned i(0); i<size; --i)` looks at element 0 only
+        if (nAnc > 0) goFurther &= (firstAnchorPos != (j - 1));
+        if (goFurther) {
+          uint64_t km, nm;
+          wave_kmer_at(X.read + (j - 1), (int)K, km, nm);
+          const int degree = dev_out_degree(X.T, MINC, km, nm, 1);
+          if (degree > 1) {
+            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j - 1, X.cov[j - 1].x}; if (nAnc == 0) firstAnchorPos = j - 1; ++nAnc; }
+            else { X.overflow |= OVF_ANCHORS; break; }
+          }
+        }
+        --j;
+      }
+    } else {
+      // :529-540: j is DEcremented (sic); with unsigned wrap-around the loop can only ever add the
+      // k-mer at pivot+1 (first iteration); afterwards goFurther is false for good (j+1 == pivot).
+      if (((j + 1) <= limit) & (nAnc < want)) {
+        if (nAnc > 0) goFurther &= (firstAnchorPos != (j + 1));
+        if (goFurther) {
+          uint64_t km, nm;
+          wave_kmer_at(X.read + (j + 1), (int)K, km, nm);
+          const int degree = dev_out_degree(X.T, MINC, km, nm, 0);
+          if (degree > 1) {
+            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j + 1, X.cov[j + 1].x}; ++nAnc; }
+            else X.overflow |= OVF_ANCHORS;
+          }
+        }
+      }
+    }
+  }
+  WSYNC();
+  if (l == 0 && nAnc > 1) gnu_sort(anc, (int)nAnc, LessAnchor{X.lambda / P.ERR});
+  WSYNC();
+  if (side == 0) X.nAncL = (int)nAnc; else X.nAncR = (int)nAnc;
+}
+
+// ------------------------------------------------------------------ getSeedAndExtension (Trail.cpp:341-437)
+struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extRef, extCand; };
+
+// growth-order restatement: the seed sits at the anchor end; extension starts at offset S
+// (K-1 walking RIGHT: Seed(0,0,K-1,K-1); K walking LEFT: Seed(len-K, len-K, len-1, len-1)).
+TALC_D SeedExt seed_and_extension(Wv& X, const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
+                                  bool withScore) {
+  const int K = (int)X.P.K;
+  const int S = X.dirRight ? K - 1 : K;
+  SeedExt r;
+  r.stop = false; r.score = 0;
+  // seq1 (database, H, rows) = the longer (reference unless strictly shorter), seq2 (query, V, cols)
+  const bool state = !(refLen < candLen);
+  const uint8_t* seq1 = state ? ref : cand; const int len1 = state ? refLen : candLen;
+  const uint8_t* seq2 = state ? cand : ref; const int len2 = state ? candLen : refLen;
+  int extCols = 0, extRows = 0;
+  const int qlen = len2 - S, dlen = len1 - S;
+  if (qlen > 0 && dlen > 0) {
+    const int need = qlen + 3;
+    XDropBuf buf;
+    buf.d1 = dp_array(X, 0, need); buf.d2 = dp_array(X, 1, need); buf.d3 = dp_array(X, 2, need);
+    if (!((uint32_t)need > X.C.dpCap && need > LDS_DP_CAP))
+      wave_xdrop(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, &X.cells);
+  }
+  const int ext1 = extRows, ext2 = extCols;            // on seq1 / seq2
+  r.extRef = state ? ext1 : ext2;
+  r.extCand = state ? ext2 : ext1;
+  r.lenRefExt = S + r.extRef;
+  r.lenHistExt = S + r.extCand;
+  r.posOnRef = X.dirRight ? (S + r.extRef) : (refLen - K - r.extRef);
+  if (max(r.lenRefExt, r.lenHistExt) >= K) {
+    if (withScore) r.score = nw_score(X, ref, r.lenRefExt, cand, r.lenHistExt, 0, -1, -1, false);
+  } else {
+    r.score = (-1) * xdrop;
+    r.stop = true;
+  }
+  return r;
+}
+
+// Trail::seedAndExtend (Trail.cpp:193-216) on slot t of set S; returns `ok`
+TALC_D bool trail_seed_and_extend(Wv& X, TrailSet& S, int t, int len, int xdrop) {
+  const SeedExt e = seed_and_extension(X, X.ref, (int)X.refLen, S.seq + (uint64_t)t * X.C.seqCap, len, xdrop, true);
+  const bool ok1 = (e.lenHistExt == len);
+  uint32_t f = S.fail[t];
+  f = ok1 ? 0u : f + 1u;
+  WSYNC();
+  if (lane_id() == 0) {
+    S.fail[t] = f;
+    S.score[t] = e.score;
+    if (X.dirRight) S.ranc[t] = e.posOnRef; else S.lanc[t] = e.posOnRef;
+  }
+  WSYNC();
+  bool ok = (f <= (uint32_t)X.P.MAX_BORDER_FAILURES);
+  ok &= !e.stop;
+  return ok;
+}
+
+// ------------------------------------------------------------------ recordEdge (Explorer.cpp:1103-1118)
+// Trajectory(trail) + trim + reshape + cutAnchors, then the fold of findBestBORDER
+// (Trajectory.cpp:306-334) into the best long / best short candidate.
+TALC_D void record_edge(Wv& X, TrailSet& S, int t, int len0) {
+  const int K = (int)X.P.K;
+  const uint8_t* path = S.seq + (uint64_t)t * X.C.seqCap;
+  const int lastScore = S.score[t];
+  const double dist = S.dist[t] / ((double)len0 + 0.01);       // Trajectory.cpp:45
+  const uint32_t lanc = (uint32_t)S.lanc[t], ranc = (uint32_t)S.ranc[t];
+  // trim (Trajectory.cpp:89-112)
+  int len = len0;
+  const uint32_t nbBases = S.fail[t] * X.P.CHECK_INTERVAL;
+  if ((uint32_t)len >= nbBases + (uint32_t)K) len = len - (int)nbBases;
+  const bool shorter = ((uint32_t)len <= X.refLen);
+  // reshape (Trajectory.cpp:114-155) with findStopPosition (:482-503)
+  int xdrop1 = (int)lastScore * (-1);
+  SeedExt cur, nxt;
+  // findStopPosition(A, B): `reference` = A, `shorterPath` = B
+  const uint8_t* A = shorter ? X.ref : path; const int lenA = shorter ? (int)X.refLen : len;
+  const uint8_t* Bq = shorter ? path : X.ref; const int lenB = shorter ? len : (int)X.refLen;
+  nxt = seed_and_extension(X, A, lenA, Bq, lenB, xdrop1, false);
+  bool goFurther = true;
+  do {
+    --xdrop1;
+    cur = nxt;
+    nxt = seed_and_extension(X, A, lenA, Bq, lenB, xdrop1, false);
+    if (nxt.lenHistExt < cur.lenHistExt) goFurther = false;
+  } while (goFurther & (xdrop1 > 0));
+  // score of the retained extension (Trail.cpp:408-434)
+  double score;
+  if (cur.stop) score = (double)cur.score;
+  else score = (double)nw_score(X, A, cur.lenRefExt, Bq, cur.lenHistExt, 0, -1, -1, false);
+  // computePercentID (Trajectory.cpp:505-528): LCS / max length
+  double idscore;
+  {
+    const int lcs = nw_score(X, A, cur.lenRefExt, Bq, cur.lenHistExt, 1, 0, 0, false);
+    const double lenMax = (double)max(cur.lenRefExt, cur.lenHistExt);
+    idscore = (double)lcs / lenMax;
+  }
+  // new sequence in growth order
+  uint8_t* tmp = X.edgeTmp;
+  uint32_t newLen;
+  if (!shorter) {
+    // prefix(path, pos) walking RIGHT / suffix(path, pos) walking LEFT == growth-order prefix of length S+ext(path)
+    newLen = (uint32_t)cur.lenRefExt;   // `reference` of findStopPosition is the path here
+    if (newLen > X.C.edgeCap) { X.overflow |= OVF_SEQ; return; }
+    wave_copy_bytes(tmp, path, newLen, false);
+  } else {
+    // path followed by the rest of the reference beyond the stop position
+    const uint32_t from = (uint32_t)cur.lenRefExt;
+    const uint32_t rest = X.refLen > from ? X.refLen - from : 0;
+    newLen = (uint32_t)len + rest;
+    if (newLen > X.C.edgeCap) { X.overflow |= OVF_SEQ; return; }
+    wave_copy_bytes(tmp, path, (uint32_t)len, false);
+    wave_copy_bytes(tmp + len, X.ref + from, rest, false);
+  }
+  WSYNC();
+  // cutAnchors HEAD/TAIL (Trajectory.cpp:168-175): drop the anchor (growth-order front); never fails
+  uint32_t cutLen = 0, cutFrom = 0;
+  if (newLen > (uint32_t)K) { cutLen = newLen - (uint32_t)K; cutFrom = (uint32_t)K; }
+  X.nEdges++;
+  EdgeCand& best = shorter ? X.bestShort : X.bestLong;
+  uint8_t* bestSeq = shorter ? X.edgeShort : X.edgeLong;
+  bool take = false;
+  if (!best.have) take = true;
+  else if (score > best.score) take = true;
+  else if (score == best.score && dist > best.dist) take = true;
+  if (take) {
+    best.have = true; best.score = score; best.dist = dist; best.idscore = idscore; best.len = cutLen;
+    best.lanc = lanc; best.ranc = ranc;
+    wave_copy_bytes(bestSeq, tmp + cutFrom, cutLen, false);
+    WSYNC();
+  }
+}
+
+// ------------------------------------------------------------------ one expansion step
+// Shared front half of oneMoreStep / oneMoreStepInTheDark: probe the table for the successors of
+// every Trail of set A (one lane per Trail, 64 at a time) and tag them (tagNextNodes).
+struct StepTags { int tags; uint32_t nc[4]; double dist[4]; };
+
+TALC_D StepTags probe_and_tag(Wv& X, int t, bool valid, bool complex) {
+  StepTags r;
+  r.tags = 0x01010101 * TAG_UNEXPECTED;
+  uint32_t cnt[4] = {0, 0, 0, 0}, jc[4] = {0, 0, 0, 0};
+  int tg[4] = {TAG_NONE, TAG_NONE, TAG_NONE, TAG_NONE};
+  double ds[4] = {0, 0, 0, 0};
+  if (valid) {
+    const uint64_t km = X.A.kmer[t], nm = X.A.nmask[t];
+    const uint32_t K = X.P.K;
+    const uint64_t succN = X.dirRight ? (nm >> 1) : (nm & ((1ULL << (K - 1)) - 1));
+    if (!succN) dev_next_counts(X.T, km, X.dirRight, cnt, jc);
+    tag_next_nodes(X.P.ALPHA, X.P.ERR, X.P.MIN_COUNT, cnt, jc, X.A.cnt[t], complex, tg, ds);
+  }
+  r.tags = (tg[0] & 0xff) | ((tg[1] & 0xff) << 8) | ((tg[2] & 0xff) << 16) | ((tg[3] & 0xff) << 24);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { r.nc[b] = cnt[b]; r.dist[b] = ds[b]; }
+  return r;
+}
+TALC_D double shfl_f64(double v, int src) {
+  long long x = __double_as_longlong(v);
+  int lo = __shfl((int)(x & 0xffffffffll), src, 64), hi = __shfl((int)(x >> 32), src, 64);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// create child `c` of set B from Trail `t` of set A with base `b`; sequences have length len -> len+1
+TALC_D void make_child(Wv& X, int t, int c, int b, int len, uint32_t count, double distAdd) {
+  const uint32_t K = X.P.K;
+  const uint64_t kmask = (1ULL << (2 * K)) - 1;
+  uint8_t* dst = X.B.seq + (uint64_t)c * X.C.seqCap;
+  const uint8_t* src = X.A.seq + (uint64_t)t * X.C.seqCap;
+  wave_copy(dst, src, (uint32_t)len);
+  if (lane_id() == 0) {
+    dst[len] = (uint8_t)b;
+    const uint64_t km = X.A.kmer[t], nm = X.A.nmask[t];
+    uint64_t km2, nm2;
+    if (X.dirRight) { km2 = ((km << 2) | (uint64_t)b) & kmask; nm2 = nm >> 1; }
+    else { km2 = ((uint64_t)b << (2 * (K - 1))) | (km >> 2); nm2 = (nm << 1) & ((1ULL << K) - 1); }
+    X.B.kmer[c] = km2; X.B.nmask[c] = nm2;
+    X.B.cnt[c] = count;
+    X.B.score[c] = X.A.score[t];
+    X.B.fail[c] = X.A.fail[t];
+    X.B.dist[c] = X.A.dist[t] + distAdd;
+    X.B.lanc[c] = X.A.lanc[t];
+    X.B.ranc[c] = X.A.ranc[t];
+  }
+  WSYNC();
+}
+
+// Trail::ThinkIveAlreadyGotThere (Trail.cpp:289-302) for child c (length len+1) against its parent t
+TALC_D bool is_cycle(Wv& X, int t, int c, int len) {
+  const int K = (int)X.P.K;
+  if (!(len > K)) return false;
+  const uint8_t* parent = X.A.seq + (uint64_t)t * X.C.seqCap;
+  const uint8_t* child = X.B.seq + (uint64_t)c * X.C.seqCap;
+  const uint8_t* pat = child + (len + 1 - K);
+  if (X.dirRight) {
+    const int p = wave_find_window(parent, len, pat, K, false);
+    return p > 0;
+  }
+  // walking LEFT the text is reversed: the reference's first occurrence is our last one, and its
+  // position 0 is the parent's tip (growth index len-K)
+  const int q = wave_find_window(parent, len, pat, K, true);
+  return q >= 0 && q != len - K;
+}
+
+TALC_D void swap_sets(Wv& X) { TrailSet t = X.A; X.A = X.B; X.B = t; }
+
+// doABitOfGardening on set B (n trails); survivors are copied into set A; returns their number
+TALC_D int garden(Wv& X, int n, int len, bool& isComplex) {
+  __shared__ int s_nk;
+  __shared__ int s_cx;
+  const int l = lane_id();
+  for (int i = l; i < n; i += 64) { X.gScores[i] = (double)X.B.score[i]; X.gDists[i] = X.B.dist[i]; }
+  WSYNC();
+  if (l == 0) {
+    bool cx = false;
+    s_nk = gardening(X.P.MAXB, n, X.gScores, X.gDists, X.gVal, X.gRank, X.gRank + (TCAP + 64), X.gKept, &cx);
+    s_cx = cx ? 1 : 0;
+  }
+  WSYNC();
+  int nk = s_nk;
+  isComplex = s_cx != 0;
+  if (nk > TCAP) { X.overflow |= OVF_TRAILS; nk = TCAP; }
+  for (int i = 0; i < nk; ++i) {
+    const uint32_t src = X.gKept[i];
+    wave_copy(X.A.seq + (uint64_t)i * X.C.seqCap, X.B.seq + (uint64_t)src * X.C.seqCap, (uint32_t)len);
+    if (l == 0) {
+      X.A.kmer[i] = X.B.kmer[src]; X.A.nmask[i] = X.B.nmask[src]; X.A.cnt[i] = X.B.cnt[src]; X.A.score[i] = X.B.score[src];
+      X.A.fail[i] = X.B.fail[src]; X.A.dist[i] = X.B.dist[src]; X.A.lanc[i] = X.B.lanc[src]; X.A.ranc[i] = X.B.ranc[src];
+    }
+  }
+  WSYNC();
+  return nk;
+}
+
+// Explorer::oneMoreStep (Explorer.cpp:546-612).  nCur trails of length len in set A.
+TALC_D int step_bridge(Wv& X, int nCur, int len, uint32_t& stepCounter) {
+  const DevParams& P = X.P;
+  const int l = lane_id();
+  const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
+  const int nAims = X.dirRight ? X.nAncR : X.nAncL;
+  int nNew = 0;
+  const bool complexIn = ((uint32_t)nCur > P.MAXB);
+  for (int base = 0; base < nCur; base += 64) {
+    const int tl = base + l;
+    const StepTags mine = probe_and_tag(X, tl, tl < nCur, complexIn);
+    const int cnt = min(64, nCur - base);
+    X.steps += (unsigned long long)cnt;
+    for (int tt = 0; tt < cnt; ++tt) {
+      const int t = base + tt;
+      const int tags = __shfl(mine.tags, tt, 64);
+      for (int i = 0; i < 4; ++i) {
+        const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
+        if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
+        const uint32_t nc = (uint32_t)__shfl((int)mine.nc[i], tt, 64);
+        const double dd = shfl_f64(mine.dist[i], tt);
+        if (nNew >= TCAP) { X.overflow |= OVF_TRAILS; continue; }
+        if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
+        make_child(X, t, nNew, i, len, nc, dd);
+        // checkAims (Trail.cpp:273-285): first aim whose k-mer equals the child's tip
+        int hit = -1;
+        {
+          const uint64_t km = X.B.kmer[nNew], nm = X.B.nmask[nNew];
+          for (int ab = 0; ab < nAims && hit < 0; ab += 64) {
+            const int a = ab + l;
+            const bool eq = (a < nAims) && (aims[a].kmer == km) && (aims[a].nmask == nm);
+            const unsigned long long m = ballot64(eq);
+            if (m) hit = ab + (int)__ffsll((long long)m) - 1;
+          }
+        }
+        if (hit >= 0) {
+          const int apos = (int)aims[hit].pos;
+          if (l == 0) { if (X.dirRight) X.B.ranc[nNew] = apos; else X.B.lanc[nNew] = apos; }
+          WSYNC();
+          // recordBridge (Explorer.cpp:1097-1101)
+          const uint32_t clen = (uint32_t)len + 1;
+          if (X.nFull >= (int)X.C.fullCap) X.overflow |= OVF_FULLPATHS;
+          else if (X.fullUsed + clen > X.C.fullPool) X.overflow |= OVF_FULLPOOL;
+          else {
+            wave_copy_bytes(X.fullPool + X.fullUsed, X.B.seq + (uint64_t)nNew * X.C.seqCap, clen, false);
+            if (l == 0) X.fullMeta[X.nFull] = FullMeta{X.fullUsed, clen, X.B.lanc[nNew], X.B.ranc[nNew], X.B.dist[nNew] / ((double)clen + 0.01)};
+            X.fullUsed += (clen + 15u) & ~15u;
+            X.nFull++;
+            WSYNC();
+          }
+          if (clen > X.refLen) continue;   // :579-582 pop_back
+          ++nNew;
+        } else {
+          if (is_cycle(X, t, nNew, len)) continue;   // :586-587 pop_back
+          ++nNew;
+        }
+      }
+    }
+  }
+  const bool complex = ((uint32_t)nNew > P.MAXB);
+  ++stepCounter;
+  int nOut;
+  if (complex & (stepCounter % P.CHECK_INTERVAL == 0)) {
+    // scoreBridges (Explorer.cpp:689-706): reference truncated to K+step+WINDOW (growth-order prefix)
+    const uint32_t bound = P.K + stepCounter + P.WINDOW;
+    const int tlen = (int)min(bound, X.refLen);
+    for (int j = 0; j < nNew; ++j) {
+      const int sc = nw_score(X, X.ref, tlen, X.B.seq + (uint64_t)j * X.C.seqCap, len + 1, 4, -3, -2, true);
+      if (l == 0) X.B.score[j] = sc;
+    }
+    WSYNC();
+    bool cx = false;
+    nOut = garden(X, nNew, len + 1, cx);
+    X.complexRegion |= cx;
+  } else {
+    swap_sets(X);
+    nOut = nNew;
+  }
+  return nOut;
+}
+
+// Explorer::scoreEdges (Explorer.cpp:709-740) on set B (n trails of length len); survivors are
+// compacted in place (set B); returns their number
+TALC_D int score_edges(Wv& X, int n, int len, int& xdrop) {
+  if (n == 0) return 0;
+  const int l = lane_id();
+  xdrop += 2;
+  int new_xdrop = 0;
+  int nSel = 0;
+  // trash paths are only needed when nobody survives: remember them by flag in gKept
+  for (int t = 0; t < n; ++t) {
+    const bool ok = trail_seed_and_extend(X, X.B, t, len, xdrop);
+    if (l == 0) X.gKept[t] = ok ? 1u : 0u;
+    if (ok) {
+      const int current_xdrop = (int)((double)X.B.score[t] * (-1));
+      if ((new_xdrop > current_xdrop) || (new_xdrop == 0)) new_xdrop = current_xdrop;
+      ++nSel;
+    }
+  }
+  WSYNC();
+  xdrop = new_xdrop;
+  if (nSel == 0) {
+    for (int t = 0; t < n; ++t) record_edge(X, X.B, t, len);
+    return 0;
+  }
+  // compact survivors to the front of set B, keeping their order
+  int w = 0;
+  for (int t = 0; t < n; ++t) {
+    if (X.gKept[t]) {
+      if (w != t) {
+        wave_copy(X.B.seq + (uint64_t)w * X.C.seqCap, X.B.seq + (uint64_t)t * X.C.seqCap, (uint32_t)len);
+        if (l == 0) {
+          X.B.kmer[w] = X.B.kmer[t]; X.B.nmask[w] = X.B.nmask[t]; X.B.cnt[w] = X.B.cnt[t]; X.B.score[w] = X.B.score[t];
+          X.B.fail[w] = X.B.fail[t]; X.B.dist[w] = X.B.dist[t]; X.B.lanc[w] = X.B.lanc[t]; X.B.ranc[w] = X.B.ranc[t];
+        }
+        WSYNC();
+      }
+      ++w;
+    }
+  }
+  WSYNC();
+  return w;
+}
+
+// Explorer::oneMoreStepInTheDark (Explorer.cpp:615-687)
+TALC_D int step_edge(Wv& X, int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, int& xdrop) {
+  const DevParams& P = X.P;
+  const int l = lane_id();
+  int nNew = 0;
+  const bool complexIn = (nCur > 7);   // :634 hard-coded
+  for (int base = 0; base < nCur; base += 64) {
+    const int tl = base + l;
+    const StepTags mine = probe_and_tag(X, tl, tl < nCur, complexIn);
+    const int cnt = min(64, nCur - base);
+    X.steps += (unsigned long long)cnt;
+    for (int tt = 0; tt < cnt; ++tt) {
+      const int t = base + tt;
+      const int tags = __shfl(mine.tags, tt, 64);
+      int counter = 0;
+      for (int i = 0; i < 4; ++i) {
+        const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
+        if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
+        ++counter;
+        const uint32_t nc = (uint32_t)__shfl((int)mine.nc[i], tt, 64);
+        const double dd = shfl_f64(mine.dist[i], tt);
+        if (nNew >= TCAP) { X.overflow |= OVF_TRAILS; continue; }
+        if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
+        make_child(X, t, nNew, i, len, nc, dd);
+        const bool cycle = is_cycle(X, t, nNew, len);
+        if (cycle || (stepCounter + 1 > PATH_MAXLENGTH)) {
+          trail_seed_and_extend(X, X.B, nNew, len + 1, xdrop);
+          record_edge(X, X.B, nNew, len + 1);
+          continue;   // pop_back
+        }
+        ++nNew;
+      }
+      if (counter == 0) {   // dead end (:657-662)
+        trail_seed_and_extend(X, X.A, t, len, xdrop);
+        record_edge(X, X.A, t, len);
+      }
+    }
+  }
+  ++stepCounter;
+  int nOut;
+  if ((stepCounter % P.CHECK_INTERVAL == 0) || ((uint32_t)nNew >= P.MAX_BORDER_PATHS)) {
+    nNew = score_edges(X, nNew, len + 1, xdrop);
+    if (nNew > 5) {
+      bool cx = false;
+      nOut = garden(X, nNew, len + 1, cx);
+      X.complexRegion |= cx;
+    } else { swap_sets(X); nOut = nNew; }
+  } else { swap_sets(X); nOut = nNew; }
+  return nOut;
+}
+
+// first Trail of a search: the start anchor (Trail.cpp:57-65)
+TALC_D void init_first_trail(Wv& X, const AnchorRec& a) {
+  const int K = (int)X.P.K;
+  wave_copy_bytes(X.A.seq, X.read + a.pos, (uint32_t)K, !X.dirRight);
+  if (lane_id() == 0) {
+    X.A.kmer[0] = a.kmer; X.A.nmask[0] = a.nmask; X.A.cnt[0] = X.cov[a.pos].x; X.A.score[0] = 0; X.A.fail[0] = 0;
+    X.A.dist[0] = 0.0;
+    X.A.lanc[0] = X.dirRight ? (int)a.pos : -1;
+    X.A.ranc[0] = X.dirRight ? -1 : (int)a.pos;
+  }
+  WSYNC();
+}
+
+// append read[from, to) to the reference buffer in growth order
+TALC_D void ref_append(Wv& X, uint32_t from, uint32_t to) {
+  if (to <= from) return;
+  const uint32_t n = to - from;
+  if (X.refLen + n > X.C.refCap) { X.overflow |= OVF_SEQ; return; }
+  wave_copy_bytes(X.ref + X.refLen, X.read + from, n, !X.dirRight);
+  X.refLen += n;
+}
+
+struct GapResult { bool found; uint32_t Le, Rs; uint32_t wOff, wLen; };
+
+// Explorer::searchBridge (Explorer.cpp:868-989) after initializeINNER(…, direction)
+TALC_D bool search_bridge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+  const DevParams& P = X.P;
+  const uint32_t K = P.K;
+  const int l = lane_id();
+  const AnchorRec* anchors = X.dirRight ? X.ancL : X.ancR;
+  const int nAnch = X.dirRight ? X.nAncL : X.nAncR;
+  const int limit = min(nAnch, (int)P.MAX_START_ANCHORS);
+  bool found = false;
+  for (int s = 0; s < limit && !found; ++s) {
+    const AnchorRec a = anchors[s];
+    const uint32_t whichStart = a.pos;
+    X.nFull = 0; X.fullUsed = 0;
+    uint32_t stepCounter = 0;
+    // gap between the start anchor and the target region (:916-918)
+    uint32_t gapLen = 0;
+    X.refLen = 0;
+    if (X.dirRight) {
+      ref_append(X, whichStart, whichStart + K);
+      if (whichStart + K < X.Rs) { gapLen = X.Rs - (whichStart + K); ref_append(X, whichStart + K, X.Rs); }
+      ref_append(X, X.Rs, X.Re + K);
+    } else {
+      ref_append(X, whichStart, whichStart + K);
+      if (X.Le + K < whichStart) { gapLen = whichStart - (X.Le + K); ref_append(X, X.Le + K, whichStart); }
+      ref_append(X, X.Ls, X.Le + K);
+      // growth order walking LEFT = reversed text: anchor, then gap, then target, each reversed,
+      // which is exactly the reverse of target+gap+anchor (:934-936)
+    }
+    WSYNC();
+    const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
+    init_first_trail(X, a);
+    int nCur = 1;
+    int len = (int)K;
+    while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
+      nCur = step_bridge(X, nCur, len, stepCounter);
+      ++len;
+      if (X.tracing && X.trace.steps) trace_rec(X, TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
+    }
+    if (X.overflow) return false;
+    if (X.nFull > 0) {
+      // :945-960 score every recorded bridge, cut its anchors; quirk :955-960 keeps the FIRST nOK
+      int nOK = 0;
+      const uint32_t limit2 = X.Re;
+      // per full path: score (edit distance), idscore, ok, new right anchor, cut (off,len)
+      // stored in gScores (score), gDists (idscore) and gKept (ok | cutLen<<1), ranc updated in meta
+      for (int t = 0; t < X.nFull; ++t) {
+        const FullMeta fm = X.fullMeta[t];
+        const uint8_t* ps = X.fullPool + fm.off;
+        double score, idv;
+        // computeEditDistance / computeIDScore (Trajectory.cpp:386-428, 337-384): both non-empty here
+        score = (double)nw_score(X, X.ref, (int)X.refLen, ps, (int)fm.len, 0, -1, -1, false);
+        const int lcs = nw_score(X, X.ref, (int)X.refLen, ps, (int)fm.len, 1, 0, 0, false);
+        idv = (double)lcs / (double)max(X.refLen, fm.len);
+        // cutAnchors INNER (Trajectory.cpp:176-197)
+        bool ok = true;
+        uint32_t cutLen = 0;
+        uint32_t ranc = (uint32_t)fm.ranc;
+        if (fm.len >= 2 * K) cutLen = fm.len - 2 * K;
+        else if ((fm.len < 2 * K) & (fm.len > K)) {
+          if (ranc + 2 * K - fm.len <= limit2) ranc = ranc + 2 * K - fm.len;
+          else ok = false;
+        } else ok = false;
+        if (l == 0) {
+          X.gScores[t] = score; X.gDists[t] = idv; X.gKept[t] = (ok ? 1u : 0u) | (cutLen << 1);
+          X.fullMeta[t].ranc = (int32_t)ranc;
+        }
+        nOK += ok ? 1 : 0;
+      }
+      WSYNC();
+      const int nCand = (nOK == X.nFull) ? X.nFull : nOK;   // :955-960
+      if (nCand > 0) {
+        // findBestBridge (Trajectory.cpp:282-303)
+        int index = 0;
+        for (int i = 1; i < nCand; ++i) if (X.gScores[i] > X.gScores[index]) index = i;
+        const int first = index;
+        for (int i = first + 1; i < nCand; ++i)
+          if (X.gScores[i] == X.gScores[first] && X.fullMeta[i].dist > X.fullMeta[index].dist) index = i;
+        const FullMeta bm = X.fullMeta[index];
+        const uint32_t flags = X.gKept[index];
+        // a path whose cutAnchors failed has an empty sequence (truncSeq stays empty)
+        const uint32_t bestLen = (flags & 1u) ? (flags >> 1) : 0u;
+        const double diff = (double)X.weakLen - (double)bestLen;
+        if (((diff < X.weakLen * 0.05) || ((X.weakLen < 6) & (bestLen < 6))) & (X.gDists[index] >= P.MIN_INNER)) {
+          X.Le = (uint32_t)bm.lanc;
+          X.Rs = (uint32_t)bm.ranc;
+          // weak sequence := path without its two anchors, stored in natural orientation
+          if (weakUsed + bestLen > X.C.weakPool) { X.overflow |= OVF_WEAKPOOL; return false; }
+          if (bestLen) wave_copy_bytes(X.weak + weakUsed, X.fullPool + bm.off + K, bestLen, !X.dirRight);
+          weakOutOff = weakUsed; weakOutLen = bestLen;
+          weakUsed += bestLen;
+          WSYNC();
+          found = true;
+        }
+      }
+    }
+  }
+  return found;
+}
+
+// Explorer::searchEdge (Explorer.cpp:992-1081) after initializeHEAD / initializeTAIL
+TALC_D bool search_edge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+  const DevParams& P = X.P;
+  const uint32_t K = P.K;
+  const AnchorRec* anchors = X.dirRight ? X.ancL : X.ancR;
+  const int nAnch = X.dirRight ? X.nAncL : X.nAncR;
+  const int limit = min(nAnch, (int)P.MAX_START_ANCHORS);
+  X.bestLong.have = false; X.bestShort.have = false; X.nEdges = 0;
+  for (int s = 0; s < limit; ++s) {
+    const AnchorRec a = anchors[s];
+    const uint32_t whichStart = a.pos;
+    uint32_t stepCounter = 0;
+    int xdrop = (int)((double)(int)P.CHECK_INTERVAL * P.FAILURE_RATE + 1.0);   // :1031
+    // currentGap = extractWeakBorderSequence(seq, whichStart, K, location) (:1035)
+    uint32_t gapLen;
+    X.refLen = 0;
+    if (X.dirRight) {   // TAIL: anchor + suffix(seq, whichStart+K)
+      gapLen = X.L - (whichStart + K);
+      ref_append(X, whichStart, X.L);
+    } else {            // HEAD: prefix(seq, whichStart) + anchor
+      gapLen = whichStart;
+      ref_append(X, whichStart, whichStart + K);
+      ref_append(X, 0, whichStart);
+    }
+    WSYNC();
+    const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
+    init_first_trail(X, a);
+    int nCur = 1;
+    int len = (int)K;
+    while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
+      nCur = step_edge(X, nCur, len, stepCounter, PATH_MAXLENGTH, xdrop);
+      ++len;
+      if (X.tracing && X.trace.steps)
+        trace_rec(X, TR_STEP, (int)stepCounter, nCur, X.nEdges, xdrop, 0.0, nullptr, 0, false);
+    }
+    if (X.overflow) return false;
+  }
+  bool found = false;
+  if (X.bestShort.have || X.bestLong.have) {
+    // sortOutBestBorder (Explorer.cpp:310-329): any long path beats every short one
+    const EdgeCand& w = X.bestLong.have ? X.bestLong : X.bestShort;
+    const uint8_t* wseq = X.bestLong.have ? X.edgeLong : X.edgeShort;
+    const double diff = (double)X.weakLen - (double)w.len;
+    double minScore;
+    if ((X.weakLen >= 300) || X.complexRegion) minScore = fmax(0.75, P.MIN_BORDER);
+    else minScore = P.MIN_BORDER;
+    if (((diff < X.weakLen * 0.05) || ((X.weakLen < 6) & (w.len < 6))) & (w.idscore >= minScore)) {
+      found = true;
+      if (weakUsed + w.len > X.C.weakPool) { X.overflow |= OVF_WEAKPOOL; return false; }
+      if (w.len) wave_copy_bytes(X.weak + weakUsed, wseq, w.len, !X.dirRight);
+      weakOutOff = weakUsed; weakOutLen = w.len;
+      weakUsed += w.len;
+      if (X.location == LOC_TAIL) X.Le = w.lanc; else X.Rs = w.ranc;
+      WSYNC();
+    }
+  }
+  return found;
+}
+
+TALC_D void trace_search(Wv& X) {
+  if (!X.tracing) return;
+  const int locRef = X.location == LOC_HEAD ? 0 : X.location == LOC_INNER ? 1 : 2;   // Location enum of the reference
+  const int nL = (X.location == LOC_HEAD) ? 0 : X.nAncL, nR = (X.location == LOC_TAIL) ? 0 : X.nAncR;
+  trace_rec(X, TR_SEARCH, locRef, X.dirRight, nL, nR, 0.0, nullptr, 0, false);
+  const int K = (int)X.P.K;
+  for (int i = 0; i < nL; ++i) trace_rec(X, TR_ANCHOR, 0, (int)X.ancL[i].pos, (int)X.ancL[i].count, 0, 0.0, X.read + X.ancL[i].pos, K, false);
+  for (int i = 0; i < nR; ++i) trace_rec(X, TR_ANCHOR, 1, (int)X.ancR[i].pos, (int)X.ancR[i].count, 0, 0.0, X.read + X.ancR[i].pos, K, false);
+}
+
+__global__ void __launch_bounds__(64)
+k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
+         const uint64_t* __restrict__ koff, const uint2* __restrict__ covAll, ReadState* __restrict__ state,
+         const uint32_t* __restrict__ regions, const uint64_t* __restrict__ regoff, uint8_t* __restrict__ outAll,
+         const uint64_t* __restrict__ outoff, const uint32_t* __restrict__ order, uint32_t n_work,
+         uint32_t* __restrict__ queue, uint8_t* __restrict__ scratchAll, uint64_t* __restrict__ counters, TraceBuf trace,
+         uint32_t traceRead) {
+  __shared__ int s_dp[3 * LDS_DP_CAP];
+  __shared__ uint32_t s_next;
+  const int l = lane_id();
+  uint8_t* slot = scratchAll + (uint64_t)blockIdx.x * C.slotBytes;
+  Wv X;
+  X.P = P; X.T = T; X.C = C;
+  X.A = make_set(slot + C.o_setA, slot + C.o_seqA);
+  X.B = make_set(slot + C.o_setB, slot + C.o_seqB);
+  X.ref = slot + C.o_ref; X.ancL = (AnchorRec*)(slot + C.o_ancL); X.ancR = (AnchorRec*)(slot + C.o_ancR);
+  X.ancPos = (uint32_t*)(slot + C.o_ancPos);
+  X.fullMeta = (FullMeta*)(slot + C.o_fullMeta); X.fullPool = slot + C.o_fullPoolB;
+  X.edgeLong = slot + C.o_edgeLong; X.edgeShort = slot + C.o_edgeShort; X.edgeTmp = slot + C.o_edgeTmp;
+  X.dpG = (int*)(slot + C.o_dp); X.dpL = s_dp;
+  {
+    uint8_t* g = slot + C.o_gard;
+    X.gScores = (double*)g; g += 8ull * (TCAP + 64);
+    X.gDists = (double*)g; g += 8ull * (TCAP + 64);
+    X.gVal = (ValIdx*)g; g += 16ull * (TCAP + 64);
+    X.gRank = (Rank4*)g; g += 32ull * (TCAP + 64);
+    X.gKept = (uint32_t*)g;
+  }
+  X.regS = (uint32_t*)(slot + C.o_regS); X.regE = (uint32_t*)(slot + C.o_regE);
+  X.wOff = (uint32_t*)(slot + C.o_wOff); X.wLen = (uint32_t*)(slot + C.o_wLen);
+  X.weak = slot + C.o_weak;
+  X.trace = trace;
+  unsigned long long totCells = 0, totSteps = 0;
+
+  while (true) {
+    WSYNC();
+    if (l == 0) s_next = atomicAdd(queue, 1u);
+    WSYNC();
+    const uint32_t qi = s_next;
+    if (qi >= n_work) break;
+    const uint32_t r = order[qi];
+    const uint64_t rb = offsets[r];
+    const uint32_t L = (uint32_t)(offsets[r + 1] - rb);
+    uint8_t* out = outAll + outoff[r];
+    const uint32_t outCap = (uint32_t)(outoff[r + 1] - outoff[r]);
+    ReadState st = state[r];
+    X.read = codes + rb; X.L = L; X.n = L >= P.K ? L - P.K + 1 : 0; X.cov = covAll + koff[r]; X.lambda = st.lambda;
+    X.cells = 0; X.steps = 0; X.overflow = 0; X.complexRegion = false;
+    X.tracing = (trace.recs != nullptr) && (r == traceRead);
+
+    if (st.status != TALC_READ_CORRECTED || st.overflow) {
+      // not corrected: pass the (encoded) read through (main.cpp:310 writes mySeqs[r] unchanged)
+      wave_copy_bytes(out, X.read, L, false);
+      if (l == 0) { state[r].outLen = L; }
+      continue;
+    }
+    const uint32_t K = P.K;
+    const uint32_t R = st.nRegions;
+    if (R > C.regCap) { X.overflow |= OVF_REGIONS; }
+    else {
+      const uint32_t* gS = regions + 2 * regoff[r];
+      const uint32_t* gE = gS + (uint32_t)(regoff[r + 1] - regoff[r]);
+      for (uint32_t i = l; i < R; i += 64) { X.regS[i] = gS[i]; X.regE[i] = gE[i]; X.wLen[i] = 0xFFFFFFFFu; X.wOff[i] = 0; }
+    }
+    WSYNC();
+    uint32_t weakUsed = 0;
+    // head / tail presence as set by setInitialStructure (Read.cpp:223-237)
+    bool headPresent = false, tailPresent = false;
+    uint32_t headLen = 0, tailLen = 0;
+    bool headCorr = false, tailCorr = false;
+    uint32_t headOff = 0, headCLen = 0, tailOff = 0, tailCLen = 0;
+    if (!X.overflow) {
+      headPresent = X.regS[0] > 0; headLen = X.regS[0];
+      const uint32_t eLast = X.regE[R - 1];
+      tailPresent = (eLast + 1 < X.n); tailLen = tailPresent ? (L - (eLast + K)) : 0;
+      // ---- inner regions (Read.cpp:346-360)
+      for (uint32_t reg = 0; reg + 1 < R && !X.overflow; ++reg) {
+        uint32_t wo = 0, wl = 0;
+        bool success = false;
+        for (int attempt = 0; attempt < 2 && !success && !X.overflow; ++attempt) {
+          // initializeINNER (Explorer.cpp:228-243)
+          X.location = LOC_INNER; X.dirRight = (attempt == 0) ? 1 : 0;
+          X.Ls = X.regS[reg]; X.Le = X.regE[reg]; X.Rs = X.regS[reg + 1]; X.Re = X.regE[reg + 1];
+          X.weakLen = (X.Rs > X.Le + K) ? (X.Rs - (X.Le + K)) : 0;
+          build_anchors(X, 0);
+          build_anchors(X, 1);
+          trace_search(X);
+          success = search_bridge(X, wo, wl, weakUsed);
+          if (X.tracing) {
+            if (success) trace_rec(X, TR_RESULT, 1, 1, (int)X.Le, (int)X.Rs, 0.0, X.weak + wo, wl, false);
+            else trace_rec(X, TR_RESULT, 1, 0, (int)X.regE[reg], (int)X.regS[reg + 1], 0.0, X.read + X.regE[reg] + K, X.weakLen, false);
+          }
+        }
+        // updateINNER (Read.cpp:294-303)
+        WSYNC();
+        if (success && l == 0) { X.regE[reg] = X.Le; X.regS[reg + 1] = X.Rs; X.wOff[reg] = wo; X.wLen[reg] = wl; }
+        WSYNC();
+      }
+      // ---- head (Read.cpp:361-367)
+      if (!X.overflow && headPresent && headLen <= P.MAX_BORDER_LEN) {
+        X.location = LOC_HEAD; X.dirRight = 0;
+        X.Rs = X.regS[0]; X.Re = X.regE[0]; X.Ls = 0; X.Le = 0;
+        X.weakLen = X.Rs;
+        X.nAncL = 0;
+        build_anchors(X, 1);
+        trace_search(X);
+        headCorr = search_edge(X, headOff, headCLen, weakUsed);
+        if (X.tracing) {
+          if (headCorr) trace_rec(X, TR_RESULT, 0, 1, 0, (int)X.Rs, 0.0, X.weak + headOff, headCLen, false);
+          else trace_rec(X, TR_RESULT, 0, 0, 0, (int)X.regS[0], 0.0, X.read, X.weakLen, false);
+        }
+        WSYNC();
+        if (headCorr && l == 0) X.regS[0] = X.Rs;   // updateHEAD (Read.cpp:305-311)
+        WSYNC();
+      }
+      // ---- tail (Read.cpp:368-374)
+      if (!X.overflow && tailPresent && tailLen <= P.MAX_BORDER_LEN) {
+        X.location = LOC_TAIL; X.dirRight = 1;
+        X.Ls = X.regS[R - 1]; X.Le = X.regE[R - 1]; X.Rs = 0; X.Re = 0;
+        X.weakLen = L - (X.Le + K);
+        X.nAncR = 0;
+        build_anchors(X, 0);
+        trace_search(X);
+        tailCorr = search_edge(X, tailOff, tailCLen, weakUsed);
+        if (X.tracing) {
+          if (tailCorr) trace_rec(X, TR_RESULT, 2, 1, (int)X.Le, 0, 0.0, X.weak + tailOff, tailCLen, false);
+          else trace_rec(X, TR_RESULT, 2, 0, (int)X.regE[R - 1], 0, 0.0, X.read + X.regE[R - 1] + K, X.weakLen, false);
+        }
+        WSYNC();
+        if (tailCorr && l == 0) X.regE[R - 1] = X.Le;   // updateTAIL (Read.cpp:313-318)
+        WSYNC();
+      }
+    }
+    totCells += X.cells; totSteps += X.steps;
+    if (X.overflow) {
+      wave_copy_bytes(out, X.read, L, false);
+      if (l == 0) { state[r].outLen = L; state[r].overflow = X.overflow; }
+      continue;
+    }
+    // ---- updateCorrSeq (Read.cpp:320-326): head + (solid, weak)* + solid + tail
+    // total length first
+    unsigned long long total = 0;
+    total += headPresent ? (headCorr ? headCLen : headLen) : 0;
+    {
+      unsigned long long part = 0;
+      for (uint32_t i = l; i < R; i += 64) {
+        part += (unsigned long long)X.regE[i] + K - X.regS[i];
+        if (i + 1 < R) {
+          if (X.wLen[i] != 0xFFFFFFFFu) part += X.wLen[i];
+          else part += (X.regS[i + 1] > X.regE[i] + K) ? (X.regS[i + 1] - (X.regE[i] + K)) : 0;
+        }
+      }
+      total += wave_sum_u64(part);
+    }
+    total += tailPresent ? (tailCorr ? tailCLen : tailLen) : 0;
+    if (total > outCap) {
+      wave_copy_bytes(out, X.read, L, false);
+      if (l == 0) { state[r].outLen = L; state[r].overflow = OVF_OUT; }
+      continue;
+    }
+    uint32_t pos = 0;
+    if (headPresent) {
+      if (headCorr) { wave_copy_bytes(out + pos, X.weak + headOff, headCLen, false); pos += headCLen; }
+      else { wave_copy_bytes(out + pos, X.read, headLen, false); pos += headLen; }
+    }
+    for (uint32_t i = 0; i < R; ++i) {
+      const uint32_t s = X.regS[i], e = X.regE[i];
+      const uint32_t sl = e + K - s;
+      wave_copy_bytes(out + pos, X.read + s, sl, false); pos += sl;
+      if (i + 1 < R) {
+        if (X.wLen[i] != 0xFFFFFFFFu) { wave_copy_bytes(out + pos, X.weak + X.wOff[i], X.wLen[i], false); pos += X.wLen[i]; }
+        else if (X.regS[i + 1] > e + K) { const uint32_t wl = X.regS[i + 1] - (e + K); wave_copy_bytes(out + pos, X.read + e + K, wl, false); pos += wl; }
+      }
+    }
+    if (tailPresent) {
+      if (tailCorr) { wave_copy_bytes(out + pos, X.weak + tailOff, tailCLen, false); pos += tailCLen; }
+      else { wave_copy_bytes(out + pos, X.read + (L - tailLen), tailLen, false); pos += tailLen; }
+    }
+    if (l == 0) state[r].outLen = pos;
+  }
+  if (l == 0) {
+    if (totSteps) atomicAdd((unsigned long long*)&counters[0], totSteps);
+    if (totCells) atomicAdd((unsigned long long*)&counters[1], totCells);
+  }
+}
+
+// ==================================================================== k_pack
+// dense output: codes -> ASCII, with the reverse complement of main.cpp:286 for corrected reads
+// under -rev.  One block per (read, 4096-base chunk) of the OUTPUT.
+__global__ void k_pack(const uint8_t* __restrict__ outAll, const uint64_t* __restrict__ outoff, const ReadState* __restrict__ state,
+                       const uint64_t* __restrict__ dense_off, uint8_t* __restrict__ dense, uint32_t n_reads, int reverse) {
+  const uint32_t r = blockIdx.x;
+  if (r >= n_reads) return;
+  const uint8_t* src = outAll + outoff[r];
+  const uint32_t len = state[r].outLen;
+  uint8_t* dst = dense + dense_off[r];
+  const bool rc = reverse && state[r].status == TALC_READ_CORRECTED && state[r].overflow == 0;
+  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+    if (rc) dst[i] = (uint8_t)code_to_ascii(complement_code(src[len - 1 - i]));
+    else dst[i] = (uint8_t)code_to_ascii(src[i]);
+  }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace talc

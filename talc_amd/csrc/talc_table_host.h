@@ -1,0 +1,185 @@
+// talc_table_host.h — host-side construction of the successor-grouped k-mer table
+// (replaces buildCDBG, Jellyfish.cpp:236-295, and decolourRepeatsFromDBG, utils.cpp:658-669).
+#pragma once
+#include <omp.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "talc_common.h"
+
+namespace talc {
+
+struct DeviceCopy {
+  Bucket* right = nullptr;
+  Bucket* left = nullptr;
+};
+
+struct HostTable {
+  talc_params p;
+  uint64_t capacity = 0;     // buckets per table
+  uint64_t nkmers = 0;       // stored k-mers == SR_DBG.size()
+  uint64_t nbuckets_right = 0, nbuckets_left = 0;
+  Bucket* right = nullptr;   // host images (calloc'ed; released after the last upload on request)
+  Bucket* left = nullptr;
+  std::map<int, DeviceCopy> dev;
+  bool frozen = false;
+
+  ~HostTable() { free(right); free(left); }
+
+  uint64_t k1mask() const { return (p.k - 1 >= 32) ? ~0ULL : ((1ULL << (2 * (p.k - 1))) - 1); }
+  uint64_t kmask() const { return (p.k >= 32) ? ~0ULL : ((1ULL << (2 * p.k)) - 1); }
+
+  static inline uint64_t home(uint64_t key, uint64_t cap) {
+    return (uint64_t)(((unsigned __int128)mix64(key) * (unsigned __int128)cap) >> 64);
+  }
+
+  bool allocate(uint64_t nKept) {
+    capacity = nKept * 2 + 64;  // load factor <= 0.5
+    right = (Bucket*)malloc(capacity * sizeof(Bucket));
+    left = (Bucket*)malloc(capacity * sizeof(Bucket));
+    if (!right || !left) return false;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)capacity; ++i) {
+      right[i].key = kEmptyKey; left[i].key = kEmptyKey;
+      for (int b = 0; b < 4; ++b) { right[i].cnt[b] = 0; right[i].jc[b] = 0; left[i].cnt[b] = 0; left[i].jc[b] = 0; }
+    }
+    return true;
+  }
+
+  // find the bucket of `key` (or the empty bucket where it would go).  bounded: stay inside
+  // [.., limit) — used by the parallel phase, where a thread must never touch another thread's
+  // bucket range — and report false if the probe sequence would leave it.
+  static inline bool findSlotBounded(Bucket* tab, uint64_t cap, uint64_t key, uint64_t limit, uint64_t& slot) {
+    uint64_t i = home(key, cap);
+    while (i < limit) {
+      if (tab[i].key == key || tab[i].key == kEmptyKey) { slot = i; return true; }
+      ++i;
+    }
+    return false;
+  }
+  static inline void findSlot(Bucket* tab, uint64_t cap, uint64_t key, uint64_t& slot) {
+    uint64_t i = home(key, cap);
+    while (true) {
+      if (tab[i].key == key || tab[i].key == kEmptyKey) { slot = i; return; }
+      if (++i == cap) i = 0;
+    }
+  }
+  static inline const Bucket* find(const Bucket* tab, uint64_t cap, uint64_t key) {
+    uint64_t i = home(key, cap);
+    while (true) {
+      if (tab[i].key == key) return &tab[i];
+      if (tab[i].key == kEmptyKey) return nullptr;
+      if (++i == cap) i = 0;
+    }
+  }
+
+  // Insert the (already count-filtered) k-mers; first duplicate wins (std::map::insert,
+  // Jellyfish.cpp:262).  Parallel over hash ranges: each thread owns a contiguous bucket range
+  // and takes the keys whose home bucket falls in it, in array order, so the winner among
+  // duplicates is the same as in a serial pass; keys whose probe sequence would cross the
+  // range end are deferred to a serial pass.
+  void insertAll(const uint64_t* kmers, const uint32_t* counts, uint64_t n) {
+    const uint64_t m1 = k1mask();
+    const uint32_t minc = p.min_count;
+    for (int which = 0; which < 2; ++which) {
+      Bucket* tab = which == 0 ? right : left;
+      int T = omp_get_max_threads();
+      if (n < 100000) T = 1;
+      std::vector<std::vector<uint64_t>> deferred(T);
+      std::vector<uint64_t> added(T, 0), newb(T, 0);
+#pragma omp parallel num_threads(T)
+      {
+        const int t = omp_get_thread_num();
+        const uint64_t lo = capacity / T * t, hi = (t == T - 1) ? capacity : capacity / T * (t + 1);
+        uint64_t nadd = 0, nb = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+          if (counts[i] < minc) continue;
+          const uint64_t km = kmers[i];
+          const uint64_t key = which == 0 ? (km >> 2) : (km & m1);
+          const uint64_t h = home(key, capacity);
+          if (h < lo || h >= hi) continue;
+          const uint32_t b = which == 0 ? (uint32_t)(km & 3) : (uint32_t)((km >> (2 * (p.k - 1))) & 3);
+          uint64_t slot;
+          if (!findSlotBounded(tab, capacity, key, hi, slot)) { deferred[t].push_back(i); continue; }
+          if (tab[slot].key == kEmptyKey) { tab[slot].key = key; nb++; }
+          if (tab[slot].cnt[b] == 0) { tab[slot].cnt[b] = counts[i]; nadd++; }
+        }
+        added[t] = nadd; newb[t] = nb;
+      }
+      uint64_t nadd = 0, nb = 0;
+      for (int t = 0; t < T; ++t) { nadd += added[t]; nb += newb[t]; }
+      for (int t = 0; t < T; ++t)
+        for (uint64_t i : deferred[t]) {
+          const uint64_t km = kmers[i];
+          const uint64_t key = which == 0 ? (km >> 2) : (km & m1);
+          const uint32_t b = which == 0 ? (uint32_t)(km & 3) : (uint32_t)((km >> (2 * (p.k - 1))) & 3);
+          uint64_t slot;
+          findSlot(tab, capacity, key, slot);
+          if (tab[slot].key == kEmptyKey) { tab[slot].key = key; nb++; }
+          if (tab[slot].cnt[b] == 0) { tab[slot].cnt[b] = counts[i]; nadd++; }
+        }
+      if (which == 0) { nkmers = nadd; nbuckets_right = nb; } else nbuckets_left = nb;
+    }
+  }
+
+  // (count, colour) of a full k-mer, host side
+  bool lookup(uint64_t km, uint32_t& cnt, uint32_t& jc) const {
+    const Bucket* b = find(right, capacity, km >> 2);
+    cnt = 0; jc = 0;
+    if (!b) return false;
+    cnt = b->cnt[km & 3]; jc = b->jc[km & 3];
+    return cnt != 0;
+  }
+  void setColour(uint64_t km, uint16_t c) {
+    Bucket* b = const_cast<Bucket*>(find(right, capacity, km >> 2));
+    if (b && b->cnt[km & 3] != 0) b->jc[km & 3] = c;
+    Bucket* l = const_cast<Bucket*>(find(left, capacity, km & k1mask()));
+    const uint32_t fb = (uint32_t)((km >> (2 * (p.k - 1))) & 3);
+    if (l && l->cnt[fb] != 0) l->jc[fb] = c;
+  }
+  uint64_t revcomp(uint64_t km) const {
+    uint64_t r = 0;
+    for (uint32_t i = 0; i < p.k; ++i) { r = (r << 2) | (3 - (km & 3)); km >>= 2; }
+    return r;
+  }
+  // Jellyfish.cpp:278-289 in list order: the k-mer, then its reverse complement
+  void colour(const uint64_t* jkmers, const int64_t* jcounts, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i) {
+      const int jc = (int)jcounts[i];
+      if (!((unsigned int)jc < p.coloured_count_thr)) continue;  // int vs unsigned compare of the reference
+      uint32_t c, j;
+      if (lookup(jkmers[i], c, j)) setColour(jkmers[i], (uint16_t)jc);
+      const uint64_t rc = revcomp(jkmers[i]);
+      if (lookup(rc, c, j)) setColour(rc, (uint16_t)jc);
+    }
+  }
+  // utils.cpp:658-669
+  void decolourRepeats() {
+    for (uint64_t b = 0; b < 4; ++b) {
+      uint64_t km = 0;
+      for (uint32_t i = 0; i < p.k; ++i) km = (km << 2) | b;
+      uint32_t c, j;
+      if (lookup(km, c, j)) setColour(km, 0);
+    }
+  }
+};
+
+// text -> packed; false if not exactly K letters of ACGT (any case)
+static inline bool packText(const char* s, size_t len, uint32_t K, uint64_t& out) {
+  if (len != K) return false;
+  uint64_t v = 0;
+  for (size_t i = 0; i < len; ++i) {
+    uint8_t c = ascii_to_code((uint8_t)s[i]);
+    if (c > 3) return false;
+    v = (v << 2) | c;
+  }
+  out = v;
+  return true;
+}
+
+}  // namespace talc

@@ -1,0 +1,241 @@
+// talc_wave.h — wavefront-cooperative primitives for the path-search kernel (gfx950, wave64).
+//
+// Execution model: ONE 64-lane wavefront per workgroup works on ONE long read.  Control flow is
+// wave-uniform (every lane evaluates the same scalar decisions); the 64 lanes are spent on
+//   * dynamic-programming sweeps (Needleman-Wunsch rows lane-skewed, x-drop anti-diagonals),
+//   * k-mer window searches (cycle detection), sequence copies, table probes.
+// All sequences are in "growth order": index 0 is the anchor end, the path grows at the back,
+// whatever the walking direction (for a LEFT walk the buffers hold the reversed text), so one
+// set of routines serves both directions.
+#pragma once
+#include <limits.h>
+
+#include "talc_common.h"
+
+namespace talc {
+
+#define WSYNC() __syncthreads()   /* one wave per workgroup: orders the wave's own LDS/global traffic */
+
+TALC_D int lane_id() { return (int)(threadIdx.x & 63u); }
+TALC_D int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+TALC_D unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off, 64));
+  return v;
+}
+TALC_D unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)__shfl_xor((long long)v, off, 64);
+  return v;
+}
+TALC_D int bcast_i32(int v, int src) { return __shfl(v, src, 64); }
+TALC_D unsigned long long ballot64(bool p) { return __ballot(p); }
+
+// dst[0..n) = src[0..n); both 16-byte aligned, n arbitrary (tail by bytes).
+TALC_D void wave_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
+  const int l = lane_id();
+  const uint32_t nv = n >> 4;
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+  uint4* d4 = reinterpret_cast<uint4*>(dst);
+  for (uint32_t i = l; i < nv; i += 64) d4[i] = s4[i];
+  for (uint32_t i = (nv << 4) + l; i < n; i += 64) dst[i] = src[i];
+}
+// unaligned byte copy, optional reversal of the source range: dst[i] = src[rev ? n-1-i : i]
+TALC_D void wave_copy_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, bool rev) {
+  for (uint32_t i = lane_id(); i < n; i += 64) dst[i] = rev ? src[n - 1 - i] : src[i];
+}
+
+// ------------------------------------------------------------------ Needleman-Wunsch score
+// globalAlignment(score-only) with Score<int,Simple>(match, mismatch, gap), linear gaps
+// (reference call sites: Trail.cpp:166,171,422; Trajectory.cpp:413), and with gap = 0,
+// mismatch = 0, match = 1 the Smith-Waterman optimum the reference uses as LCS length
+// (localAlignment(1,0,0), Trajectory.cpp:368,525): with non-negative scores and free gaps the
+// local optimum equals the global one.
+// freeBegin: AlignConfig<true,true,false,false> (first row and column 0) — in growth order this
+// serves both Trail::Overlapscore configurations (Trail.cpp:162-173).
+// H spans the DP columns, which are dealt to the lanes in blocks of B = ceil(n/64); lane l
+// sweeps row (t - l) at time step t and hands its block's last cell to lane l+1 by shuffle.
+// `row` holds n+1 ints (LDS or global).  Returns D[m][n]; *cells gets += n*m.
+TALC_D int wave_nw(const uint8_t* __restrict__ H, int n, const uint8_t* __restrict__ V, int m, int match, int mismatch,
+                   int gap, bool freeBegin, int* row, unsigned long long* cells) {
+  const int l = lane_id();
+  if (cells) *cells += (unsigned long long)n * (unsigned long long)m;
+  if (n == 0) return freeBegin ? 0 : m * gap;
+  if (m == 0) return freeBegin ? 0 : n * gap;
+  const int B = (n + 63) >> 6;
+  const int nl = (n + B - 1) / B;                 // lanes that own at least one column
+  for (int j = l; j <= n; j += 64) row[j] = freeBegin ? 0 : j * gap;
+  WSYNC();
+  const int j0 = l * B + 1;                       // first own column
+  const int j1 = min(n, j0 + B - 1);              // last own column
+  int lastOut = 0, prevLastOut = (j1 >= j0) ? (freeBegin ? 0 : j1 * gap) : 0;
+  // before a lane's first row, its "row i-1" hand-off is the row-0 value of its last column
+  lastOut = prevLastOut;
+  const int T = m + nl - 1;
+  for (int t = 1; t <= T; ++t) {
+    // values of the left neighbour: it finished row (t-1)-(l-1) = i in the previous step
+    int nbLast = __shfl_up(lastOut, 1, 64);
+    int nbPrev = __shfl_up(prevLastOut, 1, 64);
+    const int i = t - l;
+    if (l < nl && i >= 1 && i <= m) {
+      int left, diag;
+      if (l == 0) { left = freeBegin ? 0 : i * gap; diag = freeBegin ? 0 : (i - 1) * gap; }
+      else { left = nbLast; diag = nbPrev; }
+      const uint8_t vb = V[i - 1];
+      int v = left;
+      for (int j = j0; j <= j1; ++j) {
+        const int up = row[j];
+        const int d = diag + ((H[j - 1] == vb) ? match : mismatch);
+        v = max(d, max(up + gap, left + gap));
+        row[j] = v;
+        diag = up;
+        left = v;
+      }
+      prevLastOut = diag;   // D[i-1][j1]
+      lastOut = v;          // D[i][j1]
+    } else if (l < nl && i == 0) {
+      // hand-off for the neighbour's first row: row 0 of the last own column
+      prevLastOut = lastOut = freeBegin ? 0 : j1 * gap;
+    }
+  }
+  WSYNC();
+  return row[n];
+}
+
+// ------------------------------------------------------------------ gapped x-drop extension
+// SeqAn2 _extendSeedGappedXDropOneDirection (seeds_extension.h) for EXTEND_RIGHT on
+// querySeg (DP columns, V dimension) and databaseSeg (DP rows, H dimension), Score(match,
+// mismatch, gap), as used by extendSeed(..., Score(0,-1,-1), xdrop, GappedXDrop())
+// (Trail.cpp:372-373,390-391; EXTEND_LEFT is the same computation on reversed segments, which
+// is what growth order gives us).  Anti-diagonals are rolled through d1,d2,d3 (each >= cols+2
+// ints); the lanes span the live columns [minCol, maxCol) of the current anti-diagonal.
+// Outputs the "longest extension" (extCols on the query, extRows on the database) and returns
+// whether the seed moves.
+struct XDropBuf { int* d1; int* d2; int* d3; };
+
+TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg, int qlen, const uint8_t* __restrict__ dbSeg, int dlen,
+                       int match, int mismatch, int gapCost, int scoreDropOff, XDropBuf buf, int& extCols, int& extRows,
+                       unsigned long long* cells) {
+  const int l = lane_id();
+  const int cols = qlen + 1, rows = dlen + 1;
+  extCols = extRows = 0;
+  if (rows == 1 || cols == 1) return false;
+  const int undefined = INT_MIN - gapCost;
+  int* antiDiag1 = buf.d1; int* antiDiag2 = buf.d2; int* antiDiag3 = buf.d3;
+  int len1 = 0, len2 = 1, len3 = 2;
+  int minCol = 1, maxCol = 2;
+  int offset1 = 0, offset2 = 0, offset3 = 0;
+  if (l == 0) {
+    antiDiag2[0] = 0;
+    if (-gapCost > scoreDropOff) { antiDiag3[0] = undefined; antiDiag3[1] = undefined; }
+    else { antiDiag3[0] = gapCost; antiDiag3[1] = gapCost; }
+  }
+  WSYNC();
+  int antiDiagNo = 1;
+  int best = 0;
+  unsigned long long ncell = 0;
+  while (minCol < maxCol) {
+    ++antiDiagNo;
+    { int* t = antiDiag1; antiDiag1 = antiDiag2; antiDiag2 = antiDiag3; antiDiag3 = t; }
+    len1 = len2; len2 = len3;
+    offset1 = offset2; offset2 = offset3; offset3 = minCol - 1;
+    len3 = maxCol + 1 - offset3;
+    const int minScore = best - scoreDropOff;
+    if (l == 0) {  // _initAntiDiag3
+      int v0 = undefined, vN = undefined;
+      if (antiDiagNo * gapCost > minScore) {
+        if (offset3 == 0) v0 = antiDiagNo * gapCost;
+        if (antiDiagNo - maxCol == 0) vN = antiDiagNo * gapCost;
+      }
+      antiDiag3[0] = v0;
+      antiDiag3[maxCol - offset3] = vN;
+    }
+    int antiDiagBest = antiDiagNo * gapCost;
+    for (int col = minCol + l; col < maxCol; col += 64) {
+      const int i3 = col - offset3, i2 = col - offset2, i1 = col - offset1;
+      const int queryPos = col - 1, dbPos = antiDiagNo - col - 1;
+      int tmp = max(antiDiag2[i2 - 1], antiDiag2[i2]) + gapCost;
+      const int s = (querySeg[queryPos] == dbSeg[dbPos]) ? match : mismatch;
+      tmp = max(tmp, antiDiag1[i1 - 1] + s);
+      if (tmp < minScore) antiDiag3[i3] = undefined;
+      else { antiDiag3[i3] = tmp; antiDiagBest = max(antiDiagBest, tmp); }
+    }
+    ncell += (unsigned long long)(maxCol - minCol);
+    antiDiagBest = wave_max_i32(antiDiagBest);
+    best = max(best, antiDiagBest);
+    WSYNC();
+    // new minCol / maxCol: uniform scans from the two ends of the band
+    while (minCol - offset3 < len3 && antiDiag3[minCol - offset3] == undefined && minCol - offset2 - 1 < len2 &&
+           antiDiag2[minCol - offset2 - 1] == undefined)
+      ++minCol;
+    while (maxCol - offset3 > 0 && antiDiag3[maxCol - offset3 - 1] == undefined &&
+           antiDiag2[maxCol - offset2 - 1] == undefined)
+      --maxCol;
+    ++maxCol;
+    minCol = max(minCol, antiDiagNo + 2 - rows);
+    maxCol = min(maxCol, cols);
+    WSYNC();  // the scans above must finish before lane 0 overwrites antiDiag1 (next antiDiag3)
+  }
+  if (cells) *cells += ncell;
+  // longest extension
+  int longestExtensionCol = len3 + offset3 - 2;
+  int longestExtensionRow = antiDiagNo - longestExtensionCol;
+  int longestExtensionScore = antiDiag3[longestExtensionCol - offset3];
+  if (longestExtensionScore == undefined) {
+    if (antiDiag2[len2 - 2] != undefined) {
+      longestExtensionCol = len2 + offset2 - 2;
+      longestExtensionRow = antiDiagNo - 1 - longestExtensionCol;
+      longestExtensionScore = antiDiag2[longestExtensionCol - offset2];
+    } else if (len2 > 2 && antiDiag2[len2 - 3] != undefined) {
+      longestExtensionCol = len2 + offset2 - 3;
+      longestExtensionRow = antiDiagNo - 1 - longestExtensionCol;
+      longestExtensionScore = antiDiag2[longestExtensionCol - offset2];
+    }
+  }
+  if (longestExtensionScore == undefined) {
+    for (int i = 0; i < len1; ++i) {
+      const int v = antiDiag1[i];
+      if (v > longestExtensionScore) {
+        longestExtensionScore = v;
+        longestExtensionCol = i + offset1;
+        longestExtensionRow = antiDiagNo - 2 - longestExtensionCol;
+      }
+    }
+  }
+  WSYNC();
+  if (longestExtensionScore != undefined) { extCols = longestExtensionCol; extRows = longestExtensionRow; return true; }
+  return false;
+}
+
+// ------------------------------------------------------------------ k-mer window search
+// Occurrences of pat[0..K) in seq[0..len): returns the first (wantLast=false) or the last
+// (wantLast=true) start index, or -1.  Replaces Finder/Pattern<Horspool> (Trail.cpp:295-298).
+TALC_D int wave_find_window(const uint8_t* __restrict__ seq, int len, const uint8_t* __restrict__ pat, int K, bool wantLast) {
+  const int l = lane_id();
+  const int nwin = len - K + 1;
+  if (nwin <= 0) return -1;
+  if (!wantLast) {
+    for (int base = 0; base < nwin; base += 64) {
+      const int q = base + l;
+      bool eq = q < nwin;
+      if (eq) for (int i = 0; i < K; ++i) if (seq[q + i] != pat[i]) { eq = false; break; }
+      const unsigned long long m = ballot64(eq);
+      if (m) return base + (int)__ffsll((long long)m) - 1;
+    }
+    return -1;
+  }
+  for (int base = ((nwin - 1) / 64) * 64; base >= 0; base -= 64) {
+    const int q = base + l;
+    bool eq = q < nwin;
+    if (eq) for (int i = 0; i < K; ++i) if (seq[q + i] != pat[i]) { eq = false; break; }
+    const unsigned long long m = ballot64(eq);
+    if (m) return base + 63 - (int)__clzll((long long)m);
+  }
+  return -1;
+}
+
+}  // namespace talc
