@@ -165,6 +165,11 @@ uint64_t talc_batch_corrected_bytes(const talc_batch* b);
 int talc_batch_fetch_corrected(talc_ctx* c, talc_batch* b, char* out, uint64_t out_capacity,
                                uint64_t* out_offsets, int32_t* status);
 
+/* Same records, copied device-to-device into a caller-owned DEVICE buffer (e.g. a tensor that
+ * is then gathered over RCCL); out_offsets/status are host arrays and may be NULL. */
+int talc_batch_copy_corrected_device(talc_ctx* c, talc_batch* b, void* device_out, uint64_t out_capacity,
+                                     uint64_t* out_offsets, int32_t* status);
+
 /* Convenience: create + correct + fetch + destroy. */
 int talc_correct_batch(talc_ctx* c, const char* bases, const uint64_t* offsets, uint32_t n_reads,
                        char* out, uint64_t out_capacity, uint64_t* out_offsets, int32_t* status);

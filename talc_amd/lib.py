@@ -26,7 +26,8 @@ ABI_SYMBOLS = [
     "talc_table_next_counts_batch", "talc_table_destroy",
     "talc_ctx_create", "talc_ctx_destroy", "talc_batch_create", "talc_batch_destroy",
     "talc_batch_coverage", "talc_batch_fetch_coverage", "talc_batch_num_kmers", "talc_batch_num_bases",
-    "talc_batch_correct", "talc_batch_corrected_bytes", "talc_batch_fetch_corrected", "talc_correct_batch",
+    "talc_batch_correct", "talc_batch_corrected_bytes", "talc_batch_fetch_corrected",
+    "talc_batch_copy_corrected_device", "talc_correct_batch",
     "talc_ctx_get_timing", "talc_batch_trace_read",
 ]
 
@@ -122,6 +123,7 @@ def lib():
         L.talc_batch_corrected_bytes.restype = u64
         L.talc_batch_corrected_bytes.argtypes = [vp]
         L.talc_batch_fetch_corrected.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.talc_batch_copy_corrected_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.talc_correct_batch.argtypes = [vp, vp, vp, u32, vp, u64, vp, vp]
         L.talc_ctx_get_timing.argtypes = [vp, C.POINTER(Timing)]
         L.talc_batch_trace_read.restype = C.c_int64
@@ -297,6 +299,17 @@ class Batch:
         st = np.empty(self.n_reads, dtype=np.int32)
         _chk(lib().talc_batch_fetch_corrected(self.ctx._h, self._h, out.ctypes.data, total, oo.ctypes.data, st.ctypes.data))
         return out[:total], oo, st
+
+    @property
+    def corrected_bytes(self):
+        return int(lib().talc_batch_corrected_bytes(self._h))
+
+    def copy_corrected_to_device(self, device_ptr, capacity):
+        """Device-to-device copy of the dense corrected records into a caller-owned buffer."""
+        oo = np.empty(self.n_reads + 1, dtype=np.uint64)
+        st = np.empty(self.n_reads, dtype=np.int32)
+        _chk(lib().talc_batch_copy_corrected_device(self.ctx._h, self._h, C.c_void_p(device_ptr), capacity, oo.ctypes.data, st.ctypes.data))
+        return oo, st
 
     def trace(self, read_index):
         cap = 1 << 22

@@ -34,7 +34,10 @@ b = pair.ctx.batch(bases, offs)
 b.coverage()
 c, j, ko, nin = b.fetch_coverage()
 seqs = PU.seqs_of(bases, offs)
+COMP = str.maketrans("ACGTN", "TGCAN")
 for i, s in enumerate(seqs):
+    if kw.get("reverse"):
+        s = s.upper().translate(COMP)[::-1]
     oc, oj, onin = pair.otab.coverage(s)
     gc_ = c[int(ko[i]):int(ko[i + 1])]
     if len(s) >= pair.p.k:
