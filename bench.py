@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--kmers", type=int, default=50_000_000, help="distinct k-mers in the synthetic dump")
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=1200, help="reads of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="reads of the same workload timed on the CPU oracle (0 = sized for ~15 s from a pilot run)")
     ap.add_argument("--cpu-backend", choices=["flat", "map"], default="flat",
                     help="oracle table: flat hash (quick to build) or the reference's std::map")
     ap.add_argument("--no-cpu", action="store_true")
@@ -79,21 +80,17 @@ def main():
     log("setup %.1fs: table %d k-mers (%.2f GB on device), %d reads / %d bases resident" %
         (setup_s, n_table, table.device_bytes / 1e9, a.reads, n_bases))
 
+    from talc_amd import sharding as SH
+
     def gather_records():
-        """The 'trivial RCCL gather': corrected records of every rank -> rank 0 (device tensors)."""
+        """The 'trivial RCCL gather': corrected records of every rank -> rank 0 (device tensors,
+        torch.distributed over RCCL/xGMI; rank order == input order)."""
         nbytes = batch.corrected_bytes
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda")
         batch.copy_corrected_to_device(buf.data_ptr(), nbytes)
         if world == 1:
             return buf
-        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([nbytes], dtype=torch.int64, device="cuda"))
-        mx = int(max(int(s.item()) for s in sizes))
-        pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-        pad[:nbytes] = buf[:nbytes]
-        out = [torch.empty(mx, dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, out, dst=0)
-        return out
+        return SH.gather_records(buf[:nbytes], dist, rank, world, dst=0)
 
     def one_step():
         batch.correct()
@@ -196,7 +193,7 @@ def cpu_baseline(a, synth, keys, counts, bases, offs, g_out, g_off, g_st):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n = min(a.cpu_sample, len(offs) - 1)
+    n = min(a.cpu_sample, len(offs) - 1) if a.cpu_sample > 0 else 0
     q = O.params(k=a.k)
     tab = O.OracleTable(q, O.OracleTable.MAP if a.cpu_backend == "map" else O.OracleTable.FLAT)
     t0 = time.time()
@@ -207,6 +204,13 @@ def cpu_baseline(a, synth, keys, counts, bases, offs, g_out, g_off, g_st):
         tab.insert_packed(keys, counts)
     tab.decolour()
     build_s = time.time() - t0
+    if a.cpu_sample <= 0:
+        # pilot on 2 reads per core, then size the sample for ~15 s of wall time
+        n0 = min(len(offs) - 1, 2 * cores)
+        t0 = time.perf_counter()
+        tab.correct_batch(bases[: int(offs[n0])], offs[: n0 + 1].copy(), nthreads=cores)
+        per_read = (time.perf_counter() - t0) / max(n0, 1)
+        n = int(min(len(offs) - 1, max(4 * cores, 15.0 / max(per_read, 1e-6))))
     sub_off = offs[: n + 1].copy()
     sub_bases = bases[: int(sub_off[n])]
     t0 = time.perf_counter()

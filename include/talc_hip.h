@@ -126,6 +126,10 @@ int talc_table_lookup_batch(talc_table* t, int device, const uint64_t* kmers, ui
                             uint32_t* counts, uint32_t* jcounts);
 int talc_table_next_counts_batch(talc_table* t, int device, const uint64_t* kmers, uint64_t n,
                                  int direction, uint32_t* counts4, uint32_t* jcounts4);
+/* Host-side point query on the host image of the table (verification hook for the table
+ * builder; works without a GPU, before talc_table_upload or after it). */
+int talc_table_lookup_host_batch(const talc_table* t, const uint64_t* kmers, uint64_t n, uint32_t* counts,
+                                 uint32_t* jcounts);
 void talc_table_destroy(talc_table* t);
 
 /* ---------------------------------------------------------------- (2) per-read surface ---
@@ -197,6 +201,11 @@ int talc_ctx_get_timing(const talc_ctx* c, talc_timing* out);
  * same line format as the test oracle's trace; used to localise divergences.  Returns the
  * number of bytes needed (including the NUL). */
 int64_t talc_batch_trace_read(talc_ctx* c, talc_batch* b, uint32_t read_index, char* buf, uint64_t cap);
+
+/* Test hook: one wave-cooperative DP primitive on the device (mode 0: alignment score,
+ * 1: seed-and-extend, 2: k-mer window search); not part of the reference surface. */
+int talc_test_dp(talc_ctx* c, int mode, const char* a, int la, const char* b, int lb, int p0, int p1, int p2, int p3,
+                 int32_t* out);
 
 #ifdef __cplusplus
 }

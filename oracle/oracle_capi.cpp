@@ -4,6 +4,8 @@
 #include <omp.h>
 
 #include <cstdint>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <string>
@@ -270,6 +272,15 @@ int orc_gardening(const orc_params* p, const double* scores, const double* dists
   *isComplex = c ? 1 : 0;
   for (size_t i = 0; i < idx.size() && i < cap; ++i) kept[i] = idx[i];
   return (int)idx.size();
+}
+// sortAnchorsByNearest (Explorer.cpp:402-411) with the real std::sort on (pos,count) records
+void orc_sort_anchors(double cc, uint32_t* pos, uint32_t* count, int n) {
+  std::vector<anchorTuple> a;
+  for (int i = 0; i < n; ++i) a.push_back(std::make_tuple(TSeq(), pos[i], count[i]));
+  std::sort(a.begin(), a.end(), [cc](const anchorTuple& lhs, const anchorTuple& rhs) {
+    return abs((int)cc - (int)std::get<2>(lhs)) < abs((int)cc - (int)std::get<2>(rhs));
+  });
+  for (int i = 0; i < n; ++i) { pos[i] = std::get<1>(a[i]); count[i] = std::get<2>(a[i]); }
 }
 double orc_seq_error_threshold(const orc_params* p, const uint32_t* counts, uint64_t n) {
   std::vector<colouredCount> c(n);

@@ -52,6 +52,16 @@ def build_synth(force=False):
     return tgt
 
 
+def build_pure(force=False):
+    """Host build of the host/device-pure product pieces for the CPU test-suite."""
+    os.makedirs(OUT, exist_ok=True)
+    tgt = os.path.join(OUT, "libtalc_pure.so")
+    if force or _newer(tgt, _deps("pure_capi.cpp")):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-I", INCLUDE, "-I", CSRC,
+              os.path.join(CSRC, "pure_capi.cpp"), "-o", tgt])
+    return tgt
+
+
 HIP_SOURCES = ["talc_capi.hip"]
 
 
@@ -85,6 +95,7 @@ def build_oracle():
 
 def build_all(force=False):
     build_synth(force)
+    build_pure(force)
     build_hip(force)
     build_cli(force)
     build_oracle()

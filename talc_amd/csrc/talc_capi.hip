@@ -284,6 +284,14 @@ int talc_table_next_counts_batch(talc_table* t, int device, const uint64_t* kmer
   return TALC_OK;
 }
 
+int talc_table_lookup_host_batch(const talc_table* t, const uint64_t* kmers, uint64_t n, uint32_t* counts,
+                                 uint32_t* jcounts) {
+  if (!t || (n && (!kmers || !counts || !jcounts))) return fail(TALC_ERR_INVALID, "null argument");
+  if (!t->h.right) return fail(TALC_ERR_STATE, "host image released");
+  for (uint64_t i = 0; i < n; ++i) t->h.lookup(kmers[i], counts[i], jcounts[i]);
+  return TALC_OK;
+}
+
 void talc_table_destroy(talc_table* t) {
   if (!t) return;
   for (auto& kv : t->h.dev) {

@@ -70,7 +70,7 @@ struct TrailSetLayout {
   static constexpr uint64_t bytes = ranc + 4ull * TCAP;
 };
 
-static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale) {
+static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, bool tiny = false) {
   SearchCaps c;
   memset(&c, 0, sizeof c);
   const uint64_t Lm = maxLen;
@@ -81,6 +81,7 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale) 
   c.fullCap = 128 * scale;
   c.fullPool = (uint32_t)align_up((uint64_t)c.seqCap * 16 * scale, 16);
   c.dpCap = (uint32_t)align_up(std::max<uint64_t>(c.edgeCap, c.seqCap) + 8, 4);
+  if (tiny) { c.anchCap = 3; c.fullCap = 1; c.fullPool = (uint32_t)align_up((uint64_t)c.seqCap, 16); }  // test hook: force the retry pass
   c.regCap = (uint32_t)(Lm / 2 + 4);
   c.weakPool = (uint32_t)align_up(out_capacity_for(Lm), 16);
   uint64_t o = 0;
@@ -1307,6 +1308,32 @@ __global__ void k_pack(const uint8_t* __restrict__ outAll, const uint64_t* __res
   for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
     if (rc) dst[i] = (uint8_t)code_to_ascii(complement_code(src[len - 1 - i]));
     else dst[i] = (uint8_t)code_to_ascii(src[i]);
+  }
+}
+
+// ==================================================================== k_test_dp (test hook)
+// mode 0: nw_score(a, b, match, mismatch, gap, freeBegin)          -> out[0]
+// mode 1: seed_and_extension(ref=a, cand=b, xdrop, dirRight, true) -> out[0..4] = lenRefExt, lenHistExt,
+//         posOnRef, score, stop
+// mode 2: wave_find_window(a, pattern=b, wantLast=p3)              -> out[0]
+__global__ void __launch_bounds__(64)
+k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, int p1, int p2, int p3, int K,
+          int* dpG, uint32_t dpCap, int* out) {
+  __shared__ int s_dp[3 * LDS_DP_CAP];
+  Wv X;
+  memset(&X, 0, sizeof X);
+  X.P.K = (uint32_t)K;
+  X.C.dpCap = dpCap; X.dpG = dpG; X.dpL = s_dp;
+  X.dirRight = p1;
+  if (mode == 0) {
+    const int r = nw_score(X, a, la, b, lb, p0, p1, p2, p3 != 0);
+    if (lane_id() == 0) { out[0] = r; out[5] = (int)X.overflow; }
+  } else if (mode == 1) {
+    const SeedExt e = seed_and_extension(X, a, la, b, lb, p0, true);
+    if (lane_id() == 0) { out[0] = e.lenRefExt; out[1] = e.lenHistExt; out[2] = e.posOnRef; out[3] = e.score; out[4] = e.stop ? 1 : 0; out[5] = (int)X.overflow; }
+  } else {
+    const int r = wave_find_window(a, la, b, lb, p3 != 0);
+    if (lane_id() == 0) out[0] = r;
   }
 }
 

@@ -23,12 +23,12 @@ ABI_SYMBOLS = [
     "talc_abi_version", "talc_last_error", "talc_params_default", "talc_device_count",
     "talc_table_build", "talc_table_from_arrays", "talc_table_colour", "talc_table_decolour_repeats",
     "talc_table_size", "talc_table_device_bytes", "talc_table_upload", "talc_table_lookup_batch",
-    "talc_table_next_counts_batch", "talc_table_destroy",
+    "talc_table_next_counts_batch", "talc_table_lookup_host_batch", "talc_table_destroy",
     "talc_ctx_create", "talc_ctx_destroy", "talc_batch_create", "talc_batch_destroy",
     "talc_batch_coverage", "talc_batch_fetch_coverage", "talc_batch_num_kmers", "talc_batch_num_bases",
     "talc_batch_correct", "talc_batch_corrected_bytes", "talc_batch_fetch_corrected",
     "talc_batch_copy_corrected_device", "talc_correct_batch",
-    "talc_ctx_get_timing", "talc_batch_trace_read",
+    "talc_ctx_get_timing", "talc_batch_trace_read", "talc_test_dp",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
         L.talc_table_upload.argtypes = [vp, i32]
         L.talc_table_lookup_batch.argtypes = [vp, i32, vp, u64, vp, vp]
         L.talc_table_next_counts_batch.argtypes = [vp, i32, vp, u64, i32, vp, vp]
+        L.talc_table_lookup_host_batch.argtypes = [vp, vp, u64, vp, vp]
         L.talc_table_destroy.argtypes = [vp]
         L.talc_ctx_create.argtypes = [vp, C.POINTER(Params), i32, C.POINTER(vp)]
         L.talc_ctx_destroy.argtypes = [vp]
@@ -128,6 +129,7 @@ def lib():
         L.talc_ctx_get_timing.argtypes = [vp, C.POINTER(Timing)]
         L.talc_batch_trace_read.restype = C.c_int64
         L.talc_batch_trace_read.argtypes = [vp, vp, u32, vp, u64]
+        L.talc_test_dp.argtypes = [vp, i32, C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, vp]
         _LIB = L
     return _LIB
 
@@ -200,6 +202,13 @@ class Table:
         _chk(lib().talc_table_lookup_batch(self._h, device, kmers.ctypes.data, len(kmers), c.ctypes.data, j.ctypes.data))
         return c, j
 
+    def lookup_host(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        c = np.empty(len(kmers), dtype=np.uint32)
+        j = np.empty(len(kmers), dtype=np.uint32)
+        _chk(lib().talc_table_lookup_host_batch(self._h, kmers.ctypes.data, len(kmers), c.ctypes.data, j.ctypes.data))
+        return c, j
+
     def next_counts(self, kmers, direction, device=0):
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
         c = np.empty((len(kmers), 4), dtype=np.uint32)
@@ -235,6 +244,11 @@ class Context:
 
     def batch(self, bases, offsets):
         return Batch(self, bases, offsets)
+
+    def test_dp(self, mode, a, b, p0=0, p1=0, p2=0, p3=0):
+        out = np.zeros(8, dtype=np.int32)
+        _chk(lib().talc_test_dp(self._h, mode, a.encode(), len(a), b.encode(), len(b), p0, p1, p2, p3, out.ctypes.data))
+        return out
 
     def correct(self, bases, offsets):
         """One-shot: returns (out uint8 ASCII, out_offsets, status)."""

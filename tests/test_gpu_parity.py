@@ -1,0 +1,292 @@
+"""-m gpu: the parity tests proper.  Everything goes through the C ABI (libtalc_hip.so) and is
+compared bit for bit with the oracle on the same seeded inputs.  Integer / byte / index work:
+the bar is exact equality; the few doubles inside (count model, distances) are compared through
+the decisions and orderings they drive."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity_util as PU
+from talc_amd import lib as T
+
+pytestmark = pytest.mark.gpu
+COMP = str.maketrans("ACGTN", "TGCAN")
+
+
+def rc(s):
+    return s.translate(COMP)[::-1]
+
+
+def pack(reads):
+    rb = "".join(reads).encode()
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in reads])
+    return (np.frombuffer(rb, dtype=np.uint8) if rb else np.zeros(0, np.uint8)), offs
+
+
+def unpack_kmer(km, k):
+    return "".join("ACGT"[(int(km) >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+# ---------------------------------------------------------------- table surface
+def test_point_lookups_match_oracle(gpu_pair):
+    rng = np.random.default_rng(1)
+    q = np.concatenate([gpu_pair.keys[:20000], rng.integers(0, 1 << 42, 20000, dtype=np.uint64)])
+    oc, oj = gpu_pair.otab.lookup_packed(q)
+    gc, gj = gpu_pair.ttab.lookup(q)
+    assert (oc == gc).all() and (oj == gj).all()
+    assert (oc >= 2).sum() > 15000 and (oc == 0).sum() > 15000
+
+
+def test_successor_queries_match_oracle(gpu_pair):
+    """getNextCounts (Jellyfish.cpp:308-321) in both directions, order A,C,G,T."""
+    rng = np.random.default_rng(2)
+    kept = gpu_pair.keys[gpu_pair.counts >= 2][:3000]
+    q = np.concatenate([kept, rng.integers(0, 1 << 42, 500, dtype=np.uint64)])
+    for direction in (0, 1):
+        gc, gj = gpu_pair.ttab.next_counts(q, direction)
+        for i in range(0, len(q), 7):
+            oc, oj = gpu_pair.otab.next_counts(unpack_kmer(q[i], 21), direction)
+            assert oc.tolist() == gc[i].tolist() and oj.tolist() == gj[i].tolist(), (i, direction)
+        assert (gc >= 2).sum() > 500
+
+
+# ---------------------------------------------------------------- coverage kernel (Read::reCoverage)
+def test_coverage_edge_cases(gpu_pair):
+    base, offs0 = gpu_pair.reads(0, 6)
+    r = PU.seqs_of(base, offs0)
+    reads = ["", "ACGT", r[0][:21], r[0][:22], r[1].lower(), r[2][:500] + "N" + r[2][500:], "N" * 100,
+             r[3][:2048 + 20], r[3][:2048 + 21], r[4] + r[5] + r[0] + r[1],     # tile boundaries (COV_TILE = 2048)
+             "RYKMSW" + r[5][:100]]
+    bases, offs = pack(reads)
+    b = gpu_pair.ctx.batch(bases, offs)
+    b.coverage()
+    c, j, ko, nin = b.fetch_coverage()
+    for i, s in enumerate(reads):
+        oc, oj, onin = gpu_pair.otab.coverage(s)
+        gc = c[int(ko[i]):int(ko[i + 1])]
+        assert len(gc) == max(0, len(s) - 21 + 1)
+        if len(s) >= 21:
+            assert (oc == gc).all() and (oj == j[int(ko[i]):int(ko[i + 1])]).all(), i
+            assert onin == nin[i]
+    b.close()
+
+
+def test_coverage_many_reads(gpu_pair):
+    bases, offs = gpu_pair.reads(100, 400)
+    b = gpu_pair.ctx.batch(bases, offs)
+    b.coverage()
+    c, j, ko, nin = b.fetch_coverage()
+    seqs = PU.seqs_of(bases, offs)
+    for i in range(0, 400, 3):
+        oc, oj, onin = gpu_pair.otab.coverage(seqs[i])
+        if len(seqs[i]) >= 21:
+            assert (oc == c[int(ko[i]):int(ko[i + 1])]).all() and onin == nin[i]
+    t = gpu_pair.ctx.timing()
+    assert t.n_kmers == b.n_kmers and t.coverage_ms > 0
+    b.close()
+
+
+# ---------------------------------------------------------------- device DP primitives
+def test_device_alignment_scores_match_oracle(gpu_pair):
+    rnd = random.Random(3)
+    L = O.lib()
+    ctx = gpu_pair.ctx
+    for it in range(60):
+        n = rnd.choice([0, 1, 5, 40, 63, 64, 65, 130, 400, 1279, 1290, 3000])
+        m = rnd.choice([0, 1, 7, 50, 64, 200, 1300])
+        a = "".join(rnd.choice("ACGTN") for _ in range(n))
+        b = list(a[:m]) if rnd.random() < 0.5 else [rnd.choice("ACGT") for _ in range(m)]
+        for _ in range(rnd.randint(0, 6)):
+            if b:
+                b[rnd.randrange(len(b))] = rnd.choice("ACGT")
+        b = "".join(b)
+        for (mt, mm, g, fb) in ((0, -1, -1, 0), (4, -3, -2, 1), (1, 0, 0, 0), (4, -3, -2, 0)):
+            exp = L.orc_global_alignment(a.encode(), b.encode(), mt, mm, g, fb, fb, 0, 0)
+            got = ctx.test_dp(0, a, b, mt, mm, g, fb)
+            assert got[5] == 0 and got[0] == exp, (n, m, mt, fb)
+
+
+def test_device_seed_and_extension_matches_oracle(gpu_pair):
+    import ctypes as C
+    rnd = random.Random(4)
+    L = O.lib()
+    ctx = gpu_pair.ctx
+    for it in range(120):
+        n = rnd.choice([21, 22, 30, 80, 200, 600, 1400])
+        ref = [rnd.choice("ACGT") for _ in range(n)]
+        cand = list(ref)
+        for _ in range(rnd.randint(0, 12)):
+            p = rnd.randrange(len(cand))
+            x = rnd.random()
+            if x < 0.4:
+                cand[p] = rnd.choice("ACGT")
+            elif x < 0.7:
+                cand.insert(p, rnd.choice("ACGT"))
+            elif len(cand) > 25:
+                del cand[p]
+        if rnd.random() < 0.3:
+            cand = cand[: max(21, rnd.randrange(len(cand) + 1))]
+        elif rnd.random() < 0.3:
+            cand = cand + [rnd.choice("ACGT") for _ in range(rnd.randint(1, 40))]
+        ref, cand = "".join(ref), "".join(cand)
+        xdrop = rnd.randint(-1, 30)
+        for direction in (0, 1):
+            out = np.zeros(3, dtype=np.int64)
+            stop = C.c_int32()
+            sc = L.orc_seed_and_extension(ref.encode(), cand.encode(), xdrop, direction, 21, out.ctypes.data, C.byref(stop))
+            # growth order: walking LEFT the device sees both sequences reversed
+            a, b = (ref, cand) if direction else (ref[::-1], cand[::-1])
+            got = ctx.test_dp(1, a, b, xdrop, direction)
+            assert got[5] == 0
+            assert (got[0], got[1], got[2], got[3], got[4]) == (int(out[0]), int(out[1]), int(out[2]), int(sc), stop.value), \
+                (n, len(cand), xdrop, direction)
+
+
+def test_device_window_search(gpu_pair):
+    rnd = random.Random(5)
+    ctx = gpu_pair.ctx
+    for it in range(40):
+        n = rnd.choice([21, 22, 64, 65, 100, 500])
+        s = "".join(rnd.choice("AC") for _ in range(n))
+        p = rnd.randrange(0, n - 21 + 1)
+        pat = s[p:p + 21] if rnd.random() < 0.8 else "".join(rnd.choice("GT") for _ in range(21))
+        assert ctx.test_dp(2, s, pat, p3=0)[0] == s.find(pat)
+        assert ctx.test_dp(2, s, pat, p3=1)[0] == s.rfind(pat)
+
+
+# ---------------------------------------------------------------- whole hot path
+def _check(pair, first, n, nthreads=8):
+    bases, offs = pair.reads(first, n)
+    bad, (so, ost), (sg, gst) = PU.compare_correction(pair, bases, offs, nthreads=nthreads, verbose=False)
+    if bad:
+        d = PU.first_trace_diff(pair, bases, offs, bad[0])
+        raise AssertionError("reads %s differ (of %d); first trace difference of read %d: %s" % (bad[:8], n, bad[0], d))
+    return so, ost
+
+
+def test_correction_default_parameters(gpu_pair):
+    so, st = _check(gpu_pair, 1000, 600)
+    assert (st == 0).sum() > 550
+    t = gpu_pair.ctx.timing()
+    assert t.n_failed == 0 and t.n_trail_steps > 0 and t.n_dp_cells > 0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(k=18), dict(k=25), dict(k=30), dict(k=31),
+    dict(min_count=3, window_size=6, max_nb_competing_paths=5),
+    dict(alpha=1.2, sr_error_rate=0.08, min_inner_score=0.4, min_border_score=0.55),
+    dict(max_nb_competing_paths=12, window_size=15),
+], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_correction_parameter_variants(kw):
+    k = kw.pop("k", 21)
+    pair = PU.Pair(target_kmers=250_000, k=k, seed=20 + k, **kw)
+    pair.upload(0)
+    _check(pair, 0, 160)
+
+
+def test_correction_with_junction_colours():
+    pair = PU.Pair(target_kmers=300_000, k=21, seed=31, junctions=True)
+    pair.upload(0)
+    _check(pair, 0, 300)
+
+
+def test_correction_reverse_mode():
+    """-rev (main.cpp:253,286): reads from the opposite strand are corrected and flipped back;
+    reads that are not corrected stay reverse-complemented."""
+    pair = PU.Pair(target_kmers=300_000, k=21, seed=32, reverse=1)
+    pair.upload(0)
+    bases, offs = pair.reads(0, 200)
+    reads = [rc(s) for s in PU.seqs_of(bases, offs)]
+    b2, o2 = pack(reads)
+    bad, (so, ost), (sg, gst) = PU.compare_correction(pair, b2, o2, verbose=False)
+    assert not bad
+    assert (ost == 0).sum() > 150
+    # property: -rev on the opposite strand == forward correction of the original, flipped
+    fwd = PU.Pair(target_kmers=300_000, k=21, seed=32)
+    fwd.upload(0)
+    g_out, g_off, g_st = fwd.ctx.correct(bases, offs)
+    f = PU.seqs_of(g_out, g_off)
+    for i in range(200):
+        if gst[i] == 0:
+            assert sg[i] == rc(f[i])
+
+
+def test_correction_edge_inputs(gpu_pair):
+    base, offs0 = gpu_pair.reads(5000, 8)
+    r = PU.seqs_of(base, offs0)
+    reads = ["", r[0][:21], r[0][:22], r[1].lower(), r[2][:400] + "N" + r[2][400:],
+             r[3][:300] + "N" * 10 + r[3][300:900] + "RYKM" + r[3][900:], "ACGT" * 300, "A" * 500,
+             "".join(random.Random(1).choice("ACGT") for _ in range(1500)), r[4], r[5][:60], r[6] + r[7]]
+    bases, offs = pack(reads)
+    bad, (so, ost), (sg, gst) = PU.compare_correction(gpu_pair, bases, offs, verbose=False)
+    assert not bad, bad
+    assert ost[0] == 1 and ost[1] == 1           # SKIPPED_SHORT (main.cpp:262)
+    assert 2 in ost.tolist()                     # NO_SOLID_KMER reached
+
+
+def test_reads_with_many_N(gpu_pair):
+    base, offs0 = gpu_pair.reads(6000, 60)
+    rnd = random.Random(7)
+    reads = []
+    for s in PU.seqs_of(base, offs0):
+        s = list(s)
+        for _ in range(rnd.randint(1, 25)):
+            if s:
+                s[rnd.randrange(len(s))] = "N"
+        reads.append("".join(s))
+    bases, offs = pack(reads)
+    bad, _, _ = PU.compare_correction(gpu_pair, bases, offs, verbose=False)
+    assert not bad, bad
+
+
+def test_scratch_retry_pass_gives_identical_records(gpu_pair, monkeypatch):
+    """Reads whose per-wave scratch overflows are redone with 8x scratch: same records."""
+    bases, offs = gpu_pair.reads(7000, 200)
+    ref_out, ref_off, ref_st = gpu_pair.ctx.correct(bases, offs)
+    monkeypatch.setenv("TALC_TEST_TINY_CAPS", "1")
+    ctx2 = T.Context(gpu_pair.ttab, gpu_pair.p, 0)
+    out, oo, st = ctx2.correct(bases, offs)
+    t = ctx2.timing()
+    assert t.n_retried > 0 and t.n_failed == 0
+    assert np.array_equal(out, ref_out) and np.array_equal(oo, ref_off) and np.array_equal(st, ref_st)
+    ctx2.close()
+
+
+def test_batch_composition_and_order_do_not_matter(gpu_pair):
+    """Reads are independent units (main.cpp:247): one batch, several batches or a permuted batch
+    give the same record per read."""
+    bases, offs = gpu_pair.reads(8000, 300)
+    seqs = PU.seqs_of(bases, offs)
+    out, oo, st = gpu_pair.ctx.correct(bases, offs)
+    whole = PU.seqs_of(out, oo)
+    parts = []
+    for lo, hi in ((0, 7), (7, 150), (150, 300)):
+        b, o = pack(seqs[lo:hi])
+        po, poo, pst = gpu_pair.ctx.correct(b, o)
+        parts += PU.seqs_of(po, poo)
+    assert parts == whole
+    perm = np.random.default_rng(3).permutation(300)
+    b, o = pack([seqs[i] for i in perm])
+    po, poo, pst = gpu_pair.ctx.correct(b, o)
+    got = PU.seqs_of(po, poo)
+    assert [got[j] for j in np.argsort(perm)] == whole
+    assert np.array_equal(pst[np.argsort(perm)], st)
+
+
+def test_trace_hook_matches_oracle(gpu_pair):
+    bases, offs = gpu_pair.reads(9000, 3)
+    for i in range(3):
+        assert PU.first_trace_diff(gpu_pair, bases, offs, i) is None
+
+
+def test_mixed_lengths_config5_shape():
+    """BASELINE config 5 shape at small scale: K=31, reads from 500 b to 20 kb."""
+    pair = PU.Pair(target_kmers=400_000, k=31, seed=41, synth_kw=dict(mixed_lengths=1))
+    pair.upload(0)
+    so, st = _check(pair, 0, 120)
+    lens = [len(s) for s in so]
+    assert max(lens) > 8000 and min(l for l in lens if l > 31) < 1500

@@ -1,0 +1,162 @@
+"""Host build of the product's host/device-pure pieces (talc_amd/csrc/talc_pure.h, compiled by
+g++ into libtalc_pure.so) checked against the oracle and against libstdc++'s own std::sort."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+
+import oracle_lib as O
+from talc_amd import build as B
+
+ORC = O.lib()
+
+
+def pure():
+    L = C.CDLL(B.build_pure())
+    L.pure_is_expected_by_model.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_int]
+    L.pure_is_expected_by_last_node.argtypes = [C.c_double, C.c_uint32, C.c_uint32]
+    L.pure_tag_next_nodes.argtypes = [C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+    L.pure_gnu_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.pure_std_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.pure_gardening.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.pure_sort_anchors.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    return L
+
+
+P = pure()
+ORC.orc_sort_anchors.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+
+
+def test_count_model_matches_oracle():
+    rnd = random.Random(1)
+    for alpha in (2.57, 0.67, 1.96, 3.3):
+        p = O.params(alpha=alpha)
+        for _ in range(3000):
+            cc = rnd.choice([0, 1, 2, 3, 4, 5, rnd.randint(0, 50), rnd.randint(0, 5000), rnd.randint(0, 200000)])
+            nextc = rnd.choice([0, 1, 2, cc, max(0, cc - 1), cc + 1, rnd.randint(0, 60), rnd.randint(0, 300000)])
+            for cl in (0, 1):
+                assert P.pure_is_expected_by_model(alpha, nextc, cc, cl) == ORC.orc_is_expected_by_model(C.byref(p), nextc, cc, cl)
+            assert P.pure_is_expected_by_last_node(alpha, nextc, cc) == ORC.orc_is_expected_by_last_node(C.byref(p), nextc, cc)
+
+
+def test_tag_next_nodes_matches_oracle_bitwise():
+    rnd = random.Random(2)
+    for it in range(6000):
+        minc = rnd.choice([2, 2, 2, 3, 5])
+        err = rnd.choice([0.025, 0.01, 0.1])
+        alpha = rnd.choice([2.57, 2.57, 1.0])
+        p = O.params(min_count=minc, sr_error_rate=err, alpha=alpha)
+        count = rnd.choice([0, 1, 2, 3, 5, 30, 80, 400, 5000, rnd.randint(0, 100000)])
+
+        def c():
+            return rnd.choice([0, 0, 0, 1, 2, 3, count, max(0, count - rnd.randint(0, 10)), count + rnd.randint(0, 10),
+                               rnd.randint(0, 50), rnd.randint(0, 20000)])
+        cnt = np.array([c(), c(), c(), c()], dtype=np.uint32)
+        jc = np.array([rnd.choice([0, 0, 0, 5]) for _ in range(4)], dtype=np.uint32)
+        cx = rnd.random() < 0.3
+        t1, d1 = np.zeros(4, np.int32), np.zeros(4, np.float64)
+        t2, d2 = np.zeros(4, np.int32), np.zeros(4, np.float64)
+        P.pure_tag_next_nodes(alpha, err, minc, cnt.ctypes.data, jc.ctypes.data, count, int(cx), t1.ctypes.data, d1.ctypes.data)
+        ORC.orc_tag_next_nodes(C.byref(p), cnt.ctypes.data, jc.ctypes.data, count, int(cx), t2.ctypes.data, d2.ctypes.data)
+        assert t1.tolist() == t2.tolist(), (cnt, jc, count, cx)
+        # distances must agree bit for bit (NaN == NaN here: compare the raw bits)
+        assert d1.view(np.uint64).tolist() == d2.view(np.uint64).tolist(), (cnt, count)
+
+
+def _sort_both(keys):
+    n = len(keys)
+    k1 = np.array(keys, dtype=np.int32)
+    p1 = np.arange(n, dtype=np.int32)
+    k2, p2 = k1.copy(), p1.copy()
+    P.pure_gnu_sort_pairs(k1.ctypes.data, p1.ctypes.data, n)
+    P.pure_std_sort_pairs(k2.ctypes.data, p2.ctypes.data, n)
+    assert k1.tolist() == sorted(keys)
+    return p1.tolist(), p2.tolist()
+
+
+def _median3_killer(n):
+    """Musser's median-of-3 killer adapted to even n: drives introsort to its depth limit so the
+    heapsort fallback of the restated std::sort is exercised."""
+    n -= n % 2
+    k = n // 2
+    a = [0] * n
+    for i in range(1, k + 1):
+        if i % 2 == 1:
+            a[i - 1] = i
+            a[i] = k + i
+        a[k + i - 1] = 2 * i
+    return a
+
+
+def test_gnu_sort_is_libstdcxx_sort():
+    rnd = random.Random(3)
+    for it in range(1500):
+        n = rnd.choice([0, 1, 2, 5, 15, 16, 17, 18, 31, 33, 50, 64, 100, 200, 288, 500, rnd.randint(0, 1200)])
+        nd = rnd.choice([1, 2, 3, 5, 10, 50, 1000000])       # few distinct keys = many ties
+        keys = [rnd.randrange(nd) for _ in range(n)]
+        mode = rnd.random()
+        if mode < 0.15:
+            keys.sort()
+        elif mode < 0.3:
+            keys.sort(reverse=True)
+        elif mode < 0.4 and n > 4:
+            keys = [(i % 7) for i in range(n)]
+        a, b = _sort_both(keys)
+        assert a == b, (n, nd)
+    for n in (64, 128, 500, 1000, 4096):
+        a, b = _sort_both(_median3_killer(n))
+        assert a == b, n
+        keys = list(range(n // 2)) + list(range(n // 2))     # organ pipe-ish
+        a, b = _sort_both(keys)
+        assert a == b
+
+
+def test_heapsort_fallback_is_libstdcxx_partial_sort():
+    for f in ("pure_gnu_heapsort_pairs", "pure_std_heapsort_pairs"):
+        getattr(P, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    rnd = random.Random(8)
+    for it in range(800):
+        n = rnd.choice([0, 1, 2, 3, 4, 17, 18, 33, 100, rnd.randint(0, 600)])
+        nd = rnd.choice([1, 2, 4, 20, 100000])
+        keys = [rnd.randrange(nd) for _ in range(n)]
+        k1 = np.array(keys, dtype=np.int32)
+        p1 = np.arange(n, dtype=np.int32)
+        k2, p2 = k1.copy(), p1.copy()
+        P.pure_gnu_heapsort_pairs(k1.ctypes.data, p1.ctypes.data, n)
+        P.pure_std_heapsort_pairs(k2.ctypes.data, p2.ctypes.data, n)
+        assert k1.tolist() == sorted(keys) and p1.tolist() == p2.tolist(), (n, nd)
+
+
+def test_gardening_matches_oracle():
+    rnd = random.Random(4)
+    for it in range(4000):
+        maxb = rnd.choice([7, 7, 5, 10])
+        n = rnd.choice([1, 2, 6, 7, 8, 9, 12, 20, 40, 75, 150, 200, rnd.randint(1, 220)])
+        ns = rnd.choice([1, 2, 3, 5, 20, 1000])
+        nd = rnd.choice([1, 2, 3, 10, 1000])
+        scores = np.array([float(-rnd.randrange(ns) * 3) for _ in range(n)])
+        dists = np.array([rnd.randrange(nd) * 0.37 for _ in range(n)])
+        if rnd.random() < 0.1:
+            dists[rnd.randrange(n)] = float("inf")
+        p = O.params(max_nb_competing_paths=maxb)
+        k1 = np.zeros(n + maxb + 8, np.uint32)
+        k2 = np.zeros(n + maxb + 8, np.uint32)
+        c1, c2 = C.c_int32(), C.c_int32()
+        n1 = P.pure_gardening(maxb, n, scores.ctypes.data, dists.ctypes.data, k1.ctypes.data, C.byref(c1))
+        n2 = ORC.orc_gardening(C.byref(p), scores.ctypes.data, dists.ctypes.data, n, k2.ctypes.data, len(k2), C.byref(c2))
+        assert n1 == n2 and c1.value == c2.value and k1[:n1].tolist() == k2[:n2].tolist(), (maxb, n, scores, dists)
+
+
+def test_anchor_ordering_matches_std_sort():
+    rnd = random.Random(6)
+    for it in range(2000):
+        n = rnd.choice([1, 2, 3, 5, 16, 17, 30, 100, rnd.randint(1, 300)])
+        cc = rnd.choice([80.0, 1234.5, 12.0, 40000.0])
+        pos = np.arange(n, dtype=np.uint32)
+        cnt = np.array([rnd.choice([2, 3, 30, 79, 80, 81, rnd.randint(0, 3000)]) for _ in range(n)], dtype=np.uint32)
+        p1, c1, p2, c2 = pos.copy(), cnt.copy(), pos.copy(), cnt.copy()
+        P.pure_sort_anchors(cc, p1.ctypes.data, c1.ctypes.data, n)
+        ORC.orc_sort_anchors(cc, p2.ctypes.data, c2.ctypes.data, n)
+        assert p1.tolist() == p2.tolist() and c1.tolist() == c2.tolist()
