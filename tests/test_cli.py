@@ -1,0 +1,123 @@
+"""The drop-in `talc` CLI (talc_amd/csrc/talc_main.cpp, C++ host over the C ABI) against the
+oracle's restatement of the reference driver (oracle/talc_ref_main.cpp): same option table, same
+four output files (main.cpp:83-325, Settings.cpp:160-185, io.cpp:50-111, Read.cpp:394-415)."""
+import os
+import subprocess
+
+import pytest
+
+import parity_util as PU
+from talc_amd import build as B
+from talc_amd.synth import Synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TALC = os.path.join(B.OUT, "talc")
+TALC_REF = os.path.join(ROOT, "oracle", "_build", "talc_ref")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    B.build_cli()
+    assert os.path.exists(TALC) and os.path.exists(TALC_REF)
+    return TALC
+
+
+@pytest.fixture(scope="module")
+def data(tmp_path_factory):
+    d = tmp_path_factory.mktemp("clidata")
+    S = Synth(target_kmers=150_000, k=21, seed=77)
+    S.write_dump(str(d / "sr.dump"))
+    S.write_junctions(str(d / "junc.dump"))
+    S.write_fasta(str(d / "reads.fa"), 0, 60)
+    # the same reads as FASTQ with multi-line sequences
+    with open(d / "reads.fa") as f, open(d / "reads.fq", "w") as g:
+        lines = f.read().splitlines()
+        for i in range(0, len(lines), 2):
+            s = lines[i + 1]
+            g.write("@" + lines[i][1:] + "\n" + s + "\n+\n" + "I" * len(s) + "\n")
+    return d
+
+
+def run(exe, args, cwd):
+    return subprocess.run([exe] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+
+
+def files(prefix):
+    out = {}
+    for ext in (".fa", ".log", ".config.txt", ".stats_basics.txt"):
+        p = prefix + ext
+        out[ext] = open(p, "rb").read() if os.path.exists(p) else None
+    return out
+
+
+def test_cli_parse_errors_and_version(cli, tmp_path):
+    assert run(cli, [], tmp_path).returncode == 1
+    assert run(cli, ["reads.fa", "-SR", "x"], tmp_path).returncode == 1                     # -k required
+    assert run(cli, ["reads.fa", "-k", "21"], tmp_path).returncode == 1                     # -SR required
+    assert run(cli, ["reads.fa", "-k", "17", "-SR", "x"], tmp_path).returncode == 1         # range 18..31
+    assert run(cli, ["reads.fa", "-k", "21", "-SR", "x", "--MIN_COUNT", "1"], tmp_path).returncode == 1
+    assert run(cli, ["reads.fa", "-k", "21", "-SR", "x", "-qm", "kmc"], tmp_path).returncode == 1
+    assert run(cli, ["reads.fa", "-k", "21", "-SR", "x", "--bogus"], tmp_path).returncode == 1
+    r = run(cli, ["--version"], tmp_path)
+    assert r.returncode == 0 and b"1.01" in r.stdout
+    assert run(cli, ["--help"], tmp_path).returncode == 0
+
+
+def test_cli_config_and_stats_files_match_reference_text(cli, data, tmp_path):
+    """Both files are written before anything else happens (main.cpp:203-204)."""
+    args = [str(data / "missing.fa"), "-k", "21", "-SR", str(data / "sr.dump"), "--MIN_INNER_SCORE", "0.55", "--WINDOW_SIZE", "11",
+            "-j", str(data / "junc.dump")]
+    a = run(cli, args + ["-o", "gpu"], tmp_path)
+    b = run(TALC_REF, args + ["-o", "ref"], tmp_path)
+    assert a.returncode == 0 and b.returncode == 0                   # unreadable input: "ISSUE WITH INPUT FILES", exit 0
+    assert b"ISSUE WITH INPUT FILES" in a.stdout
+    fa, fb = files(str(tmp_path / "gpu")), files(str(tmp_path / "ref"))
+    assert fa[".config.txt"].replace(b"gpu", b"ref") == fb[".config.txt"]
+    assert fa[".stats_basics.txt"] == fb[".stats_basics.txt"]
+    assert b"KmerSize=21" in fa[".config.txt"] and b"MIN_INNER_SCORE=0.55" in fa[".config.txt"]
+    assert fa[".fa"] is None
+
+
+def test_cli_jellyfish2_mode_is_a_dead_path_like_the_reference(cli, data, tmp_path):
+    """-qm jellyfish2: the reference's dispatch strings never match (Jellyfish.cpp:302 vs main.cpp:123),
+    so every read longer than K logs 'No solid kmer could be found.' and passes through."""
+    args = [str(data / "reads.fa"), "-k", "21", "-SR", str(data / "sr.dump"), "-qm", "jellyfish2"]
+    a = run(cli, args + ["-o", "gpu"], tmp_path)
+    b = run(TALC_REF, args + ["-o", "ref"], tmp_path)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    fa, fb = files(str(tmp_path / "gpu")), files(str(tmp_path / "ref"))
+    assert fa[".fa"] == fb[".fa"] and fa[".log"] == fb[".log"]
+    assert fa[".log"].count(b"No solid kmer could be found.") == 60
+
+
+def test_cli_empty_table_aborts_with_exit_1(cli, data, tmp_path):
+    (tmp_path / "empty.dump").write_text("ACGTACGTACGTACGTACGTA 1\n")     # below MIN_COUNT
+    r = run(cli, [str(data / "reads.fa"), "-k", "21", "-SR", str(tmp_path / "empty.dump")], tmp_path)
+    assert r.returncode == 1 and b"The de Bruijn Graph is empty" in r.stdout
+
+
+@pytest.mark.skipif(PU.T.device_count() > 0, reason="only meaningful on a host without a GPU")
+def test_cli_fails_loudly_without_gpu(cli, data, tmp_path):
+    r = run(cli, [str(data / "reads.fa"), "-k", "21", "-SR", str(data / "sr.dump")], tmp_path)
+    assert r.returncode == 2 and b"no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["-j", "JUNC"], ["-rev"], ["--MIN_COUNT", "3", "--MAX_NB_BRANCHES", "5", "--batch-reads", "7"]],
+                         ids=["default", "junctions", "reverse", "params+small-batches"])
+def test_cli_end_to_end_files_identical_to_reference_driver(cli, data, tmp_path, extra):
+    extra = [str(data / "junc.dump") if x == "JUNC" else x for x in extra]
+    reads = str(data / "reads.fq") if "-rev" in extra else str(data / "reads.fa")
+    args = [reads, "-k", "21", "-SR", str(data / "sr.dump")] + extra
+    ref_args = [x for x in args if x not in ("--batch-reads", "7")]
+    a = run(cli, args + ["-o", "gpu"], tmp_path)
+    b = run(TALC_REF, ref_args + ["-o", "ref", "-t", "8"], tmp_path)
+    assert a.returncode == 0, a.stderr.decode()
+    assert b.returncode == 0, b.stderr.decode()
+    fa, fb = files(str(tmp_path / "gpu")), files(str(tmp_path / "ref"))
+    assert fa[".fa"] == fb[".fa"]
+    assert fa[".log"] == fb[".log"]
+    assert fa[".config.txt"].replace(b"gpu", b"ref") == fb[".config.txt"]
+    assert fa[".stats_basics.txt"] == fb[".stats_basics.txt"]
+    lines = fa[".fa"].splitlines()
+    assert len([l for l in lines if l.startswith(b">")]) == 60 and max(len(l) for l in lines if not l.startswith(b">")) == 70

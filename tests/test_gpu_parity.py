@@ -289,4 +289,4 @@ def test_mixed_lengths_config5_shape():
     pair.upload(0)
     so, st = _check(pair, 0, 120)
     lens = [len(s) for s in so]
-    assert max(lens) > 8000 and min(l for l in lens if l > 31) < 1500
+    assert max(lens) > 3000 and min(l for l in lens if l > 31) < 1500
