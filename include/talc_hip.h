@@ -203,7 +203,8 @@ int talc_ctx_get_timing(const talc_ctx* c, talc_timing* out);
 int64_t talc_batch_trace_read(talc_ctx* c, talc_batch* b, uint32_t read_index, char* buf, uint64_t cap);
 
 /* Test hook: one wave-cooperative DP primitive on the device (mode 0: alignment score,
- * 1: seed-and-extend, 2: k-mer window search); not part of the reference surface. */
+ * 1: seed-and-extend, 2: k-mer window search, 3: successor tagging); out: 12 ints; not part of the
+ * reference surface. */
 int talc_test_dp(talc_ctx* c, int mode, const char* a, int la, const char* b, int lb, int p0, int p1, int p2, int p3,
                  int32_t* out);
 

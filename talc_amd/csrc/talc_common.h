@@ -8,12 +8,28 @@
 #include <hip/hip_runtime.h>
 #define TALC_HD __host__ __device__ __forceinline__
 #define TALC_D __device__ __forceinline__
+#ifdef TALC_NO_NOINLINE
+#define TALC_DN __device__ __forceinline__
+#else
+#define TALC_DN __device__ __attribute__((noinline))
+#endif
 #else
 #define TALC_HD inline
 #define TALC_D inline
 #endif
 
 namespace talc {
+
+#if defined(__HIPCC__)
+// Explicit address spaces: pointers that travel through structs / LDS come back as generic pointers
+// and would be accessed with flat_* instructions (which tie vmcnt and lgkmcnt together); these casts
+// restore global_* / ds_* codegen.  Only ever applied to pointers known to be HBM (AS1) or LDS (AS3).
+#define TALC_AS1 __attribute__((address_space(1)))
+#define TALC_AS3 __attribute__((address_space(3)))
+typedef const uint8_t TALC_AS1* gcu8;
+typedef uint8_t TALC_AS1* gu8;
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // plain vector: usable through AS-qualified pointers
+#endif
 
 // ------------------------------------------------------------------ successor-grouped k-mer table
 // The reference's std::map<Dna5String, pair<uint,uint>> (Jellyfish.hpp:32-34) becomes two

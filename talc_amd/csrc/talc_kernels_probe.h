@@ -17,8 +17,8 @@ struct BucketRegs {
 };
 
 TALC_D BucketRegs load_bucket(const Bucket* p) {
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a = q[0], b = q[1];
+  const v4u32 TALC_AS1* q = (const v4u32 TALC_AS1*)p;   // the table is always in HBM
+  const v4u32 a = q[0], b = q[1];
   BucketRegs r;
   r.key = ((uint64_t)a.y << 32) | a.x;
   r.cnt[0] = a.z; r.cnt[1] = a.w; r.cnt[2] = b.x; r.cnt[3] = b.y;

@@ -20,7 +20,10 @@
 namespace talc {
 
 #define TCAP 288          /* slots per Trail set: <= 4*max_inner_paths children, or kept + MAXB */
-#define LDS_DP_CAP 1280   /* ints per DP array held in LDS; longer problems use the HBM arrays */
+#define NBUF (2 * TCAP)    /* sequence buffers shared by the two Trail sets (9 x 64) */
+#define LDS_DP_CAP 640    /* ints per DP array held in LDS; longer problems use the HBM arrays */
+#define HOT 16            /* Trail slots per set whose metadata lives in LDS (the common case has 1-8 Trails) */
+#define AIMS_LDS 64       /* target anchors kept in LDS for the aim check */
 
 enum : uint32_t {
   OVF_ANCHORS = 1, OVF_FULLPATHS = 2, OVF_FULLPOOL = 4, OVF_TRAILS = 8, OVF_SEQ = 16, OVF_OUT = 32, OVF_WEAKPOOL = 64,
@@ -51,7 +54,7 @@ struct SearchCaps {
   uint32_t regCap;      // regions per read
   uint32_t weakPool;    // bytes for corrected weak sequences
   uint64_t slotBytes;
-  uint64_t o_setA, o_setB, o_seqA, o_seqB, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
+  uint64_t o_setA, o_setB, o_seqPool, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
       o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak;
 };
 
@@ -67,7 +70,8 @@ struct TrailSetLayout {
   static constexpr uint64_t fail = score + 4ull * TCAP;
   static constexpr uint64_t lanc = fail + 4ull * TCAP;
   static constexpr uint64_t ranc = lanc + 4ull * TCAP;
-  static constexpr uint64_t bytes = ranc + 4ull * TCAP;
+  static constexpr uint64_t buf = ranc + 4ull * TCAP;
+  static constexpr uint64_t bytes = buf + 4ull * TCAP;
 };
 
 static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, bool tiny = false) {
@@ -88,8 +92,7 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   auto take = [&](uint64_t bytes) { uint64_t r = o; o = align_up(o + bytes, 16); return r; };
   c.o_setA = take(TrailSetLayout::bytes);
   c.o_setB = take(TrailSetLayout::bytes);
-  c.o_seqA = take((uint64_t)TCAP * c.seqCap);
-  c.o_seqB = take((uint64_t)TCAP * c.seqCap);
+  c.o_seqPool = take((uint64_t)NBUF * c.seqCap);
   c.o_ref = take(c.refCap);
   c.o_ancL = take((uint64_t)c.anchCap * sizeof(AnchorRec));
   c.o_ancR = take((uint64_t)c.anchCap * sizeof(AnchorRec));
@@ -121,7 +124,7 @@ enum { TR_REGION = 1, TR_THRESHOLD = 2, TR_SEARCH = 3, TR_ANCHOR = 4, TR_RESULT 
 // packed natural-orientation k-mer (+ N mask) of s[0..K): lanes 0..K-1 load one base each
 TALC_D void wave_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, uint64_t& nmask) {
   const int l = lane_id();
-  uint32_t c = (l < K) ? (uint32_t)s[l] : 0u;
+  uint32_t c = (l < K) ? (uint32_t)((gcu8)s)[l] : 0u;
   nmask = ballot64((l < K) && (c > 3u));
   uint64_t v = (l < K) ? ((uint64_t)(c & 3u) << (2 * (K - 1 - l))) : 0ull;
   if (c > 3u) v = 0;
@@ -322,21 +325,38 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
 // ==================================================================== k_search
 struct TrailSet {
   uint64_t* kmer; uint64_t* nmask; double* dist; uint32_t* cnt; int32_t* score; uint32_t* fail; int32_t* lanc;
-  int32_t* ranc; uint8_t* seq;
+  int32_t* ranc; uint32_t* buf;   // buf: index of the sequence buffer in the pool
 };
-TALC_D TrailSet make_set(uint8_t* meta, uint8_t* seq) {
+TALC_D TrailSet make_set(uint8_t* meta) {
   TrailSet s;
   s.kmer = (uint64_t*)(meta + TrailSetLayout::kmer); s.nmask = (uint64_t*)(meta + TrailSetLayout::nmask);
   s.dist = (double*)(meta + TrailSetLayout::dist); s.cnt = (uint32_t*)(meta + TrailSetLayout::cnt);
   s.score = (int32_t*)(meta + TrailSetLayout::score); s.fail = (uint32_t*)(meta + TrailSetLayout::fail);
   s.lanc = (int32_t*)(meta + TrailSetLayout::lanc); s.ranc = (int32_t*)(meta + TrailSetLayout::ranc);
-  s.seq = seq;
+  s.buf = (uint32_t*)(meta + TrailSetLayout::buf);
   return s;
 }
+
+// one Trail's metadata (Trail.hpp:97-108 minus the sequence)
+struct TrailRec { uint64_t kmer, nmask; double dist; uint32_t cnt; int32_t score; uint32_t fail; int32_t lanc, ranc; uint32_t buf; };
+
+// LDS traffic of a wave's own lanes is executed in order: a wavefront-scope fence (no vmcnt wait)
+// is enough to order lane 0's ds_write before the other lanes' ds_read.
+#define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// Per-wave LDS (one wavefront per workgroup).  File-scope so that every access is a ds_* op.
+__shared__ TrailRec g_hot[2 * HOT];                 // metadata of the first HOT slots of both Trail sets
+__shared__ uint64_t g_aimK[AIMS_LDS], g_aimN[AIMS_LDS];
+__shared__ uint32_t g_aimPos[AIMS_LDS];             // first AIMS_LDS target anchors
+__shared__ unsigned long long g_bloom[64];          // 4096-bit k-mer Bloom filter of the current search
+__shared__ int g_dp[3 * LDS_DP_CAP];                // x-drop stage / short DP arrays
 
 struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online (findBestBORDER is a fold)
   bool have; double score; double dist; double idscore; uint32_t len; uint32_t lanc, ranc;
 };
+
+enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_RECBRIDGE, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
+       PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_TOTAL, PF_N };
 
 struct Wv {
   // kernel constants
@@ -344,12 +364,14 @@ struct Wv {
   // read
   const uint8_t* read; uint32_t L, n; const uint2* cov; double lambda;
   // scratch
-  TrailSet A, B;
+  TrailSet G[2];                    // HBM backing store of the two Trail sets (slots >= HOT)
+  int ia;                           // which set is the current one ("competingPaths"); ia^1 = newCompetingPaths
+  uint8_t* seqPool;                 // NBUF buffers of seqCap bytes
+  unsigned long long freeMask[NBUF / 64];   // wave-uniform free bitmap of the pool
   uint8_t *ref, *fullPool, *edgeLong, *edgeShort, *edgeTmp, *weak;
   AnchorRec *ancL, *ancR; uint32_t* ancPos;
   FullMeta* fullMeta;
   int *dpG;   // 3 x dpCap ints in HBM
-  int *dpL;   // 3 x LDS_DP_CAP ints in LDS
   double* gScores; double* gDists; ValIdx* gVal; Rank4* gRank; uint32_t* gKept;
   uint32_t *regS, *regE, *wOff, *wLen;
   // explorer state (Explorer.hpp:151-174)
@@ -360,7 +382,7 @@ struct Wv {
   int nAncL, nAncR;
   uint32_t refLen;
   int nFull; uint32_t fullUsed;
-  EdgeCand bestLong, bestShort;
+  EdgeCand best2[2];               // [0] best of m_longPaths, [1] best of m_shortPaths
   int nEdges;
   // counters
   unsigned long long cells, steps;
@@ -370,23 +392,55 @@ struct Wv {
 
 enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
 
-TALC_D int* dp_array(Wv& X, int which, int need) {
-  if (need <= LDS_DP_CAP) return X.dpL + which * LDS_DP_CAP;
+// The per-wave context lives in LDS as ONE file-scope object: it is wave-uniform state (every lane
+// reads the same word = a broadcast ds_read; every lane writes the same value), costs no VGPRs,
+// and lets the heavy routines be real (non-inlined) functions without passing anything.
+__shared__ Wv g_X;
+#define X g_X
+#ifdef TALC_PROF
+__shared__ unsigned long long g_prof[PF_N];
+#endif
+
+// ---- optional in-kernel cycle accounting (diagnostic build only: -DTALC_PROF) ----
+#ifdef TALC_PROF
+#define PROF_DECL unsigned long long _pf_t
+#define PROF_BEGIN() (_pf_t = __builtin_amdgcn_s_memtime())
+#define PROF_END(cat) (g_prof[cat] += __builtin_amdgcn_s_memtime() - _pf_t)
+#else
+#define PROF_DECL
+#define PROF_BEGIN() ((void)0)
+#define PROF_END(cat) ((void)0)
+#endif
+
+#define COVX(i) (((const uint2 TALC_AS1*)X.cov)[(i)].x)
+
+// DP arrays of the slow paths (sequences longer than the register-resident routines handle):
+// always the per-wave HBM arrays, so no pointer ever mixes LDS and HBM provenance.
+TALC_D int* dp_array(int which, int need) {
   if ((uint32_t)need > X.C.dpCap) { X.overflow |= OVF_DP; }
   return X.dpG + (uint64_t)which * X.C.dpCap;
 }
 
-TALC_D int nw_score(Wv& X, const uint8_t* a, int la, const uint8_t* b, int lb, int match, int mismatch, int gap,
+#define NW_REG_NB 12
+TALC_DN int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int match, int mismatch, int gap,
                     bool freeBegin) {
   // the longer sequence spans the lanes (the score is symmetric in its arguments)
   if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
-  if ((uint32_t)(la + 1) > X.C.dpCap && la + 1 > LDS_DP_CAP) { X.overflow |= OVF_DP; return 0; }
-  int* row = dp_array(X, 0, la + 1);
-  return wave_nw(a, la, b, lb, match, mismatch, gap, freeBegin, row, &X.cells);
+  unsigned long long ncells = 0;
+  if (la <= 64 * NW_REG_NB) {
+    const int r = wave_nw_reg<NW_REG_NB>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
+    X.cells += ncells;
+    return r;
+  }
+  if ((uint32_t)(la + 1) > X.C.dpCap) { X.overflow |= OVF_DP; return 0; }
+  int* row = dp_array(0, la + 1);
+  const int r = wave_nw(a, la, b, lb, match, mismatch, gap, freeBegin, row, ncells);
+  X.cells += ncells;
+  return r;
 }
 
 // ------------------------------------------------------------------ trace helpers
-TALC_D void trace_rec(Wv& X, int kind, int a, int b, int c, int d, double x, const uint8_t* s, uint32_t slen, bool rev) {
+TALC_D void trace_rec(int kind, int a, int b, int c, int d, double x, const uint8_t* s, uint32_t slen, bool rev) {
   if (!X.tracing) return;
   WSYNC();
   if (lane_id() == 0) {
@@ -402,10 +456,79 @@ TALC_D void trace_rec(Wv& X, int kind, int a, int b, int c, int d, double x, con
   WSYNC();
 }
 
+// ------------------------------------------------------------------ sequence buffer pool
+// Trails are flat byte strings; a child that is the LAST successor of its parent takes over the
+// parent's buffer and just appends its base (the common single-path case copies nothing), the
+// other children get a fresh buffer and copy.  The free bitmap is wave-uniform register state.
+TALC_D void pool_reset() {
+#pragma unroll
+  for (int w = 0; w < NBUF / 64; ++w) X.freeMask[w] = ~0ull;
+}
+TALC_D int pool_alloc() {
+  int id = -1;
+#pragma unroll
+  for (int w = 0; w < NBUF / 64; ++w) {
+    if (id < 0 && X.freeMask[w]) {
+      const int b = (int)__ffsll((long long)X.freeMask[w]) - 1;
+      X.freeMask[w] &= ~(1ull << b);
+      id = w * 64 + b;
+    }
+  }
+  if (id < 0) { X.overflow |= OVF_TRAILS; id = 0; }
+  return id;
+}
+TALC_D void pool_free(uint32_t id) {
+#pragma unroll
+  for (int w = 0; w < NBUF / 64; ++w) if ((int)(id >> 6) == w) X.freeMask[w] |= (1ull << (id & 63));
+}
+// slots >= HOT live in HBM; these are real calls so that the optimiser never merges an LDS and an
+// HBM access into one access through a pointer of mixed provenance (which would become flat_*)
+TALC_DN TrailRec tr_get_slow(int set, int t) {
+  const TrailSet& S = X.G[set];
+  TrailRec r;
+  r.kmer = S.kmer[t]; r.nmask = S.nmask[t]; r.dist = S.dist[t]; r.cnt = S.cnt[t]; r.score = S.score[t]; r.fail = S.fail[t];
+  r.lanc = S.lanc[t]; r.ranc = S.ranc[t]; r.buf = S.buf[t];
+  return r;
+}
+TALC_DN void tr_put_slow(int set, int t, TrailRec r) {
+  TrailSet& S = X.G[set];
+  S.kmer[t] = r.kmer; S.nmask[t] = r.nmask; S.dist[t] = r.dist; S.cnt[t] = r.cnt; S.score[t] = r.score; S.fail[t] = r.fail;
+  S.lanc[t] = r.lanc; S.ranc[t] = r.ranc; S.buf[t] = r.buf;
+}
+TALC_D TrailRec tr_get(int set, int t) {
+  if (t < HOT) return g_hot[set * HOT + t];
+  return tr_get_slow(set, t);
+}
+TALC_D void tr_put(int set, int t, const TrailRec& r) {   // call from ONE lane
+  if (t < HOT) { g_hot[set * HOT + t] = r; return; }
+  tr_put_slow(set, t, r);
+}
+TALC_D void tr_sync(int t) { if (t < HOT) LSYNC(); else WSYNC(); }
+TALC_D uint32_t tr_buf(int set, int t) { return (t < HOT) ? g_hot[set * HOT + t].buf : tr_get_slow(set, t).buf; }
+TALC_D uint8_t* trail_seq(int set, int t) { return X.seqPool + (uint64_t)tr_buf(set, t) * X.C.seqCap; }
+
+// Bloom filter over the k-mers of the current search (one 64-bit word per lane = 4096 bits, two
+// probes): a superset of every live Trail's k-mers, so "definitely absent" skips the exact window
+// search of ThinkIveAlreadyGotThere (Trail.cpp:289-302); "maybe" falls through to it.
+TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
+  const uint64_t h = mix64(kmer ^ (nmask * 0x9E3779B97F4A7C15ULL));
+  const int l1 = (int)(h & 63), b1 = (int)((h >> 6) & 63), l2 = (int)((h >> 12) & 63), b2 = (int)((h >> 18) & 63);
+  const unsigned long long w1 = g_bloom[l1], w2 = g_bloom[l2];
+  const bool maybe = ((w1 >> b1) & 1ull) && ((w2 >> b2) & 1ull);
+  if (lane_id() == 0) {
+    g_bloom[l1] = w1 | (1ull << b1);
+    g_bloom[l2] = (l1 == l2 ? (w1 | (1ull << b1)) : w2) | (1ull << b2);
+  }
+  LSYNC();
+  return maybe;
+}
+
 // ------------------------------------------------------------------ anchors (Explorer.cpp:413-543)
 // side 0: anchorLEFTHandSide (walks the LEFT region leftwards from its end, degree towards RIGHT)
 // side 1: anchorRIGHTHandSide (walks the RIGHT region rightwards from its start, degree towards LEFT)
-TALC_D void build_anchors(Wv& X, int side) {
+TALC_DN void build_anchors(int side) {
+  PROF_DECL;
+  PROF_BEGIN();
   const DevParams& P = X.P;
   const uint32_t K = P.K, MINC = P.MIN_COUNT;
   const int l = lane_id();
@@ -417,7 +540,7 @@ TALC_D void build_anchors(Wv& X, int side) {
   const uint32_t pivot = side == 0 ? re : rs;
   const uint32_t limit = side == 0 ? rs : re;
   bool goFurther = true;
-  double current_count = (double)X.cov[pivot].x;
+  double current_count = (double)COVX(pivot);
   double next_count = 0;
   uint32_t j = pivot;
   uint32_t nPos = 0;
@@ -425,7 +548,7 @@ TALC_D void build_anchors(Wv& X, int side) {
   nPos = 1;
   if (side == 0) {
     while (goFurther & (j >= limit + 1)) {
-      next_count = (double)X.cov[j - 1].x;
+      next_count = (double)COVX(j - 1);
       if ((next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) goFurther = is_expected_by_last_node(P.ALPHA, (uint32_t)next_count, (uint32_t)current_count);
       else goFurther = false;
       if (!goFurther & (current_count >= MINC) & (next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) {
@@ -438,7 +561,7 @@ TALC_D void build_anchors(Wv& X, int side) {
     }
   } else {
     while (goFurther & ((j + 1) <= limit)) {
-      next_count = (double)X.cov[j + 1].x;
+      next_count = (double)COVX(j + 1);
       if ((next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) goFurther = is_expected_by_last_node(P.ALPHA, (uint32_t)next_count, (uint32_t)current_count);
       else goFurther = false;
       if (!goFurther & (current_count >= MINC) & (next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) {
@@ -461,7 +584,7 @@ TALC_D void build_anchors(Wv& X, int side) {
     if ((a == 0) || ((a != 0) & (degree > 1))) {
       // Explorer.cpp:454,520: the recorded count is m_coverage[anc] (loop index), not [anchorPos[anc]]
       if (nAnc < cap) {
-        if (l == 0) anc[nAnc] = AnchorRec{km, nm, pos, X.cov[a].x};
+        if (l == 0) anc[nAnc] = AnchorRec{km, nm, pos, COVX(a)};
         if (nAnc == 0) firstAnchorPos = pos;
         ++nAnc;
       } else X.overflow |= OVF_ANCHORS;
@@ -480,7 +603,7 @@ TALC_D void build_anchors(Wv& X, int side) {
           wave_kmer_at(X.read + (j - 1), (int)K, km, nm);
           const int degree = dev_out_degree(X.T, MINC, km, nm, 1);
           if (degree > 1) {
-            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j - 1, X.cov[j - 1].x}; if (nAnc == 0) firstAnchorPos = j - 1; ++nAnc; }
+            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j - 1, COVX(j - 1)}; if (nAnc == 0) firstAnchorPos = j - 1; ++nAnc; }
             else { X.overflow |= OVF_ANCHORS; break; }
           }
         }
@@ -496,7 +619,7 @@ TALC_D void build_anchors(Wv& X, int side) {
           wave_kmer_at(X.read + (j + 1), (int)K, km, nm);
           const int degree = dev_out_degree(X.T, MINC, km, nm, 0);
           if (degree > 1) {
-            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j + 1, X.cov[j + 1].x}; ++nAnc; }
+            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j + 1, COVX(j + 1)}; ++nAnc; }
             else X.overflow |= OVF_ANCHORS;
           }
         }
@@ -507,6 +630,7 @@ TALC_D void build_anchors(Wv& X, int side) {
   if (l == 0 && nAnc > 1) gnu_sort(anc, (int)nAnc, LessAnchor{X.lambda / P.ERR});
   WSYNC();
   if (side == 0) X.nAncL = (int)nAnc; else X.nAncR = (int)nAnc;
+  PROF_END(PF_ANCHORS);
 }
 
 // ------------------------------------------------------------------ getSeedAndExtension (Trail.cpp:341-437)
@@ -514,8 +638,9 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 
 // growth-order restatement: the seed sits at the anchor end; extension starts at offset S
 // (K-1 walking RIGHT: Seed(0,0,K-1,K-1); K walking LEFT: Seed(len-K, len-K, len-1, len-1)).
-TALC_D SeedExt seed_and_extension(Wv& X, const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
+TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
                                   bool withScore) {
+  PROF_DECL;
   const int K = (int)X.P.K;
   const int S = X.dirRight ? K - 1 : K;
   SeedExt r;
@@ -525,13 +650,22 @@ TALC_D SeedExt seed_and_extension(Wv& X, const uint8_t* ref, int refLen, const u
   const uint8_t* seq1 = state ? ref : cand; const int len1 = state ? refLen : candLen;
   const uint8_t* seq2 = state ? cand : ref; const int len2 = state ? candLen : refLen;
   int extCols = 0, extRows = 0;
+  unsigned long long ncells = 0;
   const int qlen = len2 - S, dlen = len1 - S;
   if (qlen > 0 && dlen > 0) {
-    const int need = qlen + 3;
-    XDropBuf buf;
-    buf.d1 = dp_array(X, 0, need); buf.d2 = dp_array(X, 1, need); buf.d3 = dp_array(X, 2, need);
-    if (!((uint32_t)need > X.C.dpCap && need > LDS_DP_CAP))
-      wave_xdrop(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, &X.cells);
+    PROF_BEGIN();
+    int rc = wave_xdrop_reg(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, (uint8_t TALC_AS3*)g_dp, 3 * LDS_DP_CAP * 4, extCols, extRows,
+                            ncells);
+    if (rc < 0) {   // band wider than a wavefront: LDS / HBM anti-diagonals
+      const int need = qlen + 3;
+      XDropBuf buf;
+      buf.d1 = dp_array(0, need); buf.d2 = dp_array(1, need); buf.d3 = dp_array(2, need);
+      extCols = extRows = 0;
+      if (!((uint32_t)need > X.C.dpCap))
+        wave_xdrop(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, ncells);
+    }
+    PROF_END(PF_XDROP);
+    X.cells += ncells;
   }
   const int ext1 = extRows, ext2 = extCols;            // on seq1 / seq2
   r.extRef = state ? ext1 : ext2;
@@ -540,7 +674,7 @@ TALC_D SeedExt seed_and_extension(Wv& X, const uint8_t* ref, int refLen, const u
   r.lenHistExt = S + r.extCand;
   r.posOnRef = X.dirRight ? (S + r.extRef) : (refLen - K - r.extRef);
   if (max(r.lenRefExt, r.lenHistExt) >= K) {
-    if (withScore) r.score = nw_score(X, ref, r.lenRefExt, cand, r.lenHistExt, 0, -1, -1, false);
+    if (withScore) { PROF_BEGIN(); r.score = nw_score(ref, r.lenRefExt, cand, r.lenHistExt, 0, -1, -1, false); PROF_END(PF_EXTNW); }
   } else {
     r.score = (-1) * xdrop;
     r.stop = true;
@@ -549,19 +683,17 @@ TALC_D SeedExt seed_and_extension(Wv& X, const uint8_t* ref, int refLen, const u
 }
 
 // Trail::seedAndExtend (Trail.cpp:193-216) on slot t of set S; returns `ok`
-TALC_D bool trail_seed_and_extend(Wv& X, TrailSet& S, int t, int len, int xdrop) {
-  const SeedExt e = seed_and_extension(X, X.ref, (int)X.refLen, S.seq + (uint64_t)t * X.C.seqCap, len, xdrop, true);
+TALC_DN bool trail_seed_and_extend(int set, int t, int len, int xdrop) {
+  WSYNC();   // the Trail's last bases were appended by lane 0: make them visible to the DP lanes
+  TrailRec r = tr_get(set, t);
+  const SeedExt e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)r.buf * X.C.seqCap, len, xdrop, true);
   const bool ok1 = (e.lenHistExt == len);
-  uint32_t f = S.fail[t];
-  f = ok1 ? 0u : f + 1u;
-  WSYNC();
-  if (lane_id() == 0) {
-    S.fail[t] = f;
-    S.score[t] = e.score;
-    if (X.dirRight) S.ranc[t] = e.posOnRef; else S.lanc[t] = e.posOnRef;
-  }
-  WSYNC();
-  bool ok = (f <= (uint32_t)X.P.MAX_BORDER_FAILURES);
+  r.fail = ok1 ? 0u : r.fail + 1u;
+  r.score = e.score;
+  if (X.dirRight) r.ranc = e.posOnRef; else r.lanc = e.posOnRef;
+  if (lane_id() == 0) tr_put(set, t, r);
+  tr_sync(t);
+  bool ok = (r.fail <= (uint32_t)X.P.MAX_BORDER_FAILURES);
   ok &= !e.stop;
   return ok;
 }
@@ -569,15 +701,18 @@ TALC_D bool trail_seed_and_extend(Wv& X, TrailSet& S, int t, int len, int xdrop)
 // ------------------------------------------------------------------ recordEdge (Explorer.cpp:1103-1118)
 // Trajectory(trail) + trim + reshape + cutAnchors, then the fold of findBestBORDER
 // (Trajectory.cpp:306-334) into the best long / best short candidate.
-TALC_D void record_edge(Wv& X, TrailSet& S, int t, int len0) {
+TALC_DN void record_edge(int set, int t, int len0) {
+  PROF_DECL;
   const int K = (int)X.P.K;
-  const uint8_t* path = S.seq + (uint64_t)t * X.C.seqCap;
-  const int lastScore = S.score[t];
-  const double dist = S.dist[t] / ((double)len0 + 0.01);       // Trajectory.cpp:45
-  const uint32_t lanc = (uint32_t)S.lanc[t], ranc = (uint32_t)S.ranc[t];
+  WSYNC();
+  const TrailRec tr = tr_get(set, t);
+  const uint8_t* path = X.seqPool + (uint64_t)tr.buf * X.C.seqCap;
+  const int lastScore = tr.score;
+  const double dist = tr.dist / ((double)len0 + 0.01);       // Trajectory.cpp:45
+  const uint32_t lanc = (uint32_t)tr.lanc, ranc = (uint32_t)tr.ranc;
   // trim (Trajectory.cpp:89-112)
   int len = len0;
-  const uint32_t nbBases = S.fail[t] * X.P.CHECK_INTERVAL;
+  const uint32_t nbBases = tr.fail * X.P.CHECK_INTERVAL;
   if ((uint32_t)len >= nbBases + (uint32_t)K) len = len - (int)nbBases;
   const bool shorter = ((uint32_t)len <= X.refLen);
   // reshape (Trajectory.cpp:114-155) with findStopPosition (:482-503)
@@ -586,22 +721,23 @@ TALC_D void record_edge(Wv& X, TrailSet& S, int t, int len0) {
   // findStopPosition(A, B): `reference` = A, `shorterPath` = B
   const uint8_t* A = shorter ? X.ref : path; const int lenA = shorter ? (int)X.refLen : len;
   const uint8_t* Bq = shorter ? path : X.ref; const int lenB = shorter ? len : (int)X.refLen;
-  nxt = seed_and_extension(X, A, lenA, Bq, lenB, xdrop1, false);
+  nxt = seed_and_extension(A, lenA, Bq, lenB, xdrop1, false);
   bool goFurther = true;
   do {
     --xdrop1;
     cur = nxt;
-    nxt = seed_and_extension(X, A, lenA, Bq, lenB, xdrop1, false);
+    nxt = seed_and_extension(A, lenA, Bq, lenB, xdrop1, false);
     if (nxt.lenHistExt < cur.lenHistExt) goFurther = false;
   } while (goFurther & (xdrop1 > 0));
   // score of the retained extension (Trail.cpp:408-434)
+  PROF_BEGIN();
   double score;
   if (cur.stop) score = (double)cur.score;
-  else score = (double)nw_score(X, A, cur.lenRefExt, Bq, cur.lenHistExt, 0, -1, -1, false);
+  else score = (double)nw_score(A, cur.lenRefExt, Bq, cur.lenHistExt, 0, -1, -1, false);
   // computePercentID (Trajectory.cpp:505-528): LCS / max length
   double idscore;
   {
-    const int lcs = nw_score(X, A, cur.lenRefExt, Bq, cur.lenHistExt, 1, 0, 0, false);
+    const int lcs = nw_score(A, cur.lenRefExt, Bq, cur.lenHistExt, 1, 0, 0, false);
     const double lenMax = (double)max(cur.lenRefExt, cur.lenHistExt);
     idscore = (double)lcs / lenMax;
   }
@@ -627,7 +763,9 @@ TALC_D void record_edge(Wv& X, TrailSet& S, int t, int len0) {
   uint32_t cutLen = 0, cutFrom = 0;
   if (newLen > (uint32_t)K) { cutLen = newLen - (uint32_t)K; cutFrom = (uint32_t)K; }
   X.nEdges++;
-  EdgeCand& best = shorter ? X.bestShort : X.bestLong;
+  // (no references / pointers into the LDS context are formed conditionally: copy in, copy out)
+  const int bi = shorter ? 1 : 0;
+  EdgeCand best = X.best2[bi];
   uint8_t* bestSeq = shorter ? X.edgeShort : X.edgeLong;
   bool take = false;
   if (!best.have) take = true;
@@ -636,28 +774,31 @@ TALC_D void record_edge(Wv& X, TrailSet& S, int t, int len0) {
   if (take) {
     best.have = true; best.score = score; best.dist = dist; best.idscore = idscore; best.len = cutLen;
     best.lanc = lanc; best.ranc = ranc;
+    X.best2[bi] = best;
     wave_copy_bytes(bestSeq, tmp + cutFrom, cutLen, false);
     WSYNC();
   }
+  PROF_END(PF_EDGEMISC);
 }
 
 // ------------------------------------------------------------------ one expansion step
 // Shared front half of oneMoreStep / oneMoreStepInTheDark: probe the table for the successors of
-// every Trail of set A (one lane per Trail, 64 at a time) and tag them (tagNextNodes).
+// every Trail of the current set (one lane per Trail, 64 at a time) and tag them (tagNextNodes).
 struct StepTags { int tags; uint32_t nc[4]; double dist[4]; };
 
-TALC_D StepTags probe_and_tag(Wv& X, int t, bool valid, bool complex) {
+TALC_D StepTags probe_and_tag(int t, bool valid, bool complex) {
   StepTags r;
-  r.tags = 0x01010101 * TAG_UNEXPECTED;
   uint32_t cnt[4] = {0, 0, 0, 0}, jc[4] = {0, 0, 0, 0};
   int tg[4] = {TAG_NONE, TAG_NONE, TAG_NONE, TAG_NONE};
   double ds[4] = {0, 0, 0, 0};
   if (valid) {
-    const uint64_t km = X.A.kmer[t], nm = X.A.nmask[t];
+    uint64_t km, nm; uint32_t lc;
+    if (t < HOT) { const TrailRec& h = g_hot[X.ia * HOT + t]; km = h.kmer; nm = h.nmask; lc = h.cnt; }
+    else { const TrailRec h = tr_get_slow(X.ia, t); km = h.kmer; nm = h.nmask; lc = h.cnt; }
     const uint32_t K = X.P.K;
     const uint64_t succN = X.dirRight ? (nm >> 1) : (nm & ((1ULL << (K - 1)) - 1));
     if (!succN) dev_next_counts(X.T, km, X.dirRight, cnt, jc);
-    tag_next_nodes(X.P.ALPHA, X.P.ERR, X.P.MIN_COUNT, cnt, jc, X.A.cnt[t], complex, tg, ds);
+    tag_next_nodes(X.P.ALPHA, X.P.ERR, X.P.MIN_COUNT, cnt, jc, lc, complex, tg, ds);
   }
   r.tags = (tg[0] & 0xff) | ((tg[1] & 0xff) << 8) | ((tg[2] & 0xff) << 16) | ((tg[3] & 0xff) << 24);
 #pragma unroll
@@ -670,36 +811,42 @@ TALC_D double shfl_f64(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// create child `c` of set B from Trail `t` of set A with base `b`; sequences have length len -> len+1
-TALC_D void make_child(Wv& X, int t, int c, int b, int len, uint32_t count, double distAdd) {
+// create child `c` of the new set from Trail `t` of the current set with base `b`; sequences have
+// length len -> len+1.  inherit: the child takes over the parent's sequence buffer (it is the
+// parent's last successor).  Returns the child's tip k-mer (wave-uniform).
+TALC_D void make_child(int t, int c, int b, int len, uint32_t count, double distAdd, bool inherit, uint64_t& km2,
+                       uint64_t& nm2) {
   const uint32_t K = X.P.K;
   const uint64_t kmask = (1ULL << (2 * K)) - 1;
-  uint8_t* dst = X.B.seq + (uint64_t)c * X.C.seqCap;
-  const uint8_t* src = X.A.seq + (uint64_t)t * X.C.seqCap;
-  wave_copy(dst, src, (uint32_t)len);
-  if (lane_id() == 0) {
-    dst[len] = (uint8_t)b;
-    const uint64_t km = X.A.kmer[t], nm = X.A.nmask[t];
-    uint64_t km2, nm2;
-    if (X.dirRight) { km2 = ((km << 2) | (uint64_t)b) & kmask; nm2 = nm >> 1; }
-    else { km2 = ((uint64_t)b << (2 * (K - 1))) | (km >> 2); nm2 = (nm << 1) & ((1ULL << K) - 1); }
-    X.B.kmer[c] = km2; X.B.nmask[c] = nm2;
-    X.B.cnt[c] = count;
-    X.B.score[c] = X.A.score[t];
-    X.B.fail[c] = X.A.fail[t];
-    X.B.dist[c] = X.A.dist[t] + distAdd;
-    X.B.lanc[c] = X.A.lanc[t];
-    X.B.ranc[c] = X.A.ranc[t];
+  const TrailRec p = tr_get(X.ia, t);
+  uint32_t cbuf = p.buf;
+  if (!inherit) {
+    cbuf = (uint32_t)pool_alloc();
+    WSYNC();   // bases appended by lane 0 in earlier steps must be visible to the copying lanes
+    wave_copy(X.seqPool + (uint64_t)cbuf * X.C.seqCap, X.seqPool + (uint64_t)p.buf * X.C.seqCap, (uint32_t)len);
   }
-  WSYNC();
+  if (X.dirRight) { km2 = ((p.kmer << 2) | (uint64_t)b) & kmask; nm2 = p.nmask >> 1; }
+  else { km2 = ((uint64_t)b << (2 * (K - 1))) | (p.kmer >> 2); nm2 = (p.nmask << 1) & ((1ULL << K) - 1); }
+  if (lane_id() == 0) {
+    ((gu8)X.seqPool)[(uint64_t)cbuf * X.C.seqCap + len] = (uint8_t)b;
+    TrailRec ch;
+    ch.kmer = km2; ch.nmask = nm2; ch.cnt = count; ch.score = p.score; ch.fail = p.fail; ch.dist = p.dist + distAdd;
+    ch.lanc = p.lanc; ch.ranc = p.ranc; ch.buf = cbuf;
+    tr_put(X.ia ^ 1, c, ch);
+  }
+  tr_sync(c);
 }
 
-// Trail::ThinkIveAlreadyGotThere (Trail.cpp:289-302) for child c (length len+1) against its parent t
-TALC_D bool is_cycle(Wv& X, int t, int c, int len) {
+// Trail::ThinkIveAlreadyGotThere (Trail.cpp:289-302) for child c (length len+1, tip km2/nm2)
+// against its parent t
+TALC_D bool is_cycle(int t, int c, int len, uint64_t km2, uint64_t nm2) {
   const int K = (int)X.P.K;
+  const bool maybe = bloom_query_insert(km2, nm2);
   if (!(len > K)) return false;
-  const uint8_t* parent = X.A.seq + (uint64_t)t * X.C.seqCap;
-  const uint8_t* child = X.B.seq + (uint64_t)c * X.C.seqCap;
+  if (!maybe) return false;   // the k-mer occurs nowhere in this search so far
+  WSYNC();
+  const uint8_t* parent = trail_seq(X.ia, t);
+  const uint8_t* child = trail_seq(X.ia ^ 1, c);
   const uint8_t* pat = child + (len + 1 - K);
   if (X.dirRight) {
     const int p = wave_find_window(parent, len, pat, K, false);
@@ -711,14 +858,17 @@ TALC_D bool is_cycle(Wv& X, int t, int c, int len) {
   return q >= 0 && q != len - K;
 }
 
-TALC_D void swap_sets(Wv& X) { TrailSet t = X.A; X.A = X.B; X.B = t; }
+TALC_D void swap_sets() { X.ia ^= 1; }
 
-// doABitOfGardening on set B (n trails); survivors are copied into set A; returns their number
-TALC_D int garden(Wv& X, int n, int len, bool& isComplex) {
+// doABitOfGardening on the new set (n trails); survivors are copied into the other set, which
+// becomes the current one; returns their number
+TALC_DN int garden(int n, int len, bool& isComplex) {
   __shared__ int s_nk;
   __shared__ int s_cx;
   const int l = lane_id();
-  for (int i = l; i < n; i += 64) { X.gScores[i] = (double)X.B.score[i]; X.gDists[i] = X.B.dist[i]; }
+  const int ib = X.ia ^ 1;   // the Trails to rank
+  WSYNC();
+  for (int i = l; i < n; i += 64) { const TrailRec r = tr_get(ib, i); X.gScores[i] = (double)r.score; X.gDists[i] = r.dist; }
   WSYNC();
   if (l == 0) {
     bool cx = false;
@@ -731,32 +881,47 @@ TALC_D int garden(Wv& X, int n, int len, bool& isComplex) {
   if (nk > TCAP) { X.overflow |= OVF_TRAILS; nk = TCAP; }
   for (int i = 0; i < nk; ++i) {
     const uint32_t src = X.gKept[i];
-    wave_copy(X.A.seq + (uint64_t)i * X.C.seqCap, X.B.seq + (uint64_t)src * X.C.seqCap, (uint32_t)len);
-    if (l == 0) {
-      X.A.kmer[i] = X.B.kmer[src]; X.A.nmask[i] = X.B.nmask[src]; X.A.cnt[i] = X.B.cnt[src]; X.A.score[i] = X.B.score[src];
-      X.A.fail[i] = X.B.fail[src]; X.A.dist[i] = X.B.dist[src]; X.A.lanc[i] = X.B.lanc[src]; X.A.ranc[i] = X.B.ranc[src];
-    }
+    TrailRec r = tr_get(ib, (int)src);
+    const uint32_t nb = (uint32_t)pool_alloc();
+    wave_copy(X.seqPool + (uint64_t)nb * X.C.seqCap, X.seqPool + (uint64_t)r.buf * X.C.seqCap, (uint32_t)len);
+    r.buf = nb;
+    if (l == 0) tr_put(X.ia, i, r);
   }
   WSYNC();
+  for (int i = 0; i < n; ++i) pool_free(tr_buf(ib, i));
   return nk;
 }
 
-// Explorer::oneMoreStep (Explorer.cpp:546-612).  nCur trails of length len in set A.
-TALC_D int step_bridge(Wv& X, int nCur, int len, uint32_t& stepCounter) {
+TALC_D int last_successor(int tags) {
+  int lastI = -1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int tg = (int)(int8_t)((tags >> (8 * i)) & 0xff); if (tg != TAG_NONE && tg != TAG_UNEXPECTED) lastI = i; }
+  return lastI;
+}
+
+// Explorer::oneMoreStep (Explorer.cpp:546-612).  nCur trails of length len in the current set.
+TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
+  PROF_DECL;
   const DevParams& P = X.P;
   const int l = lane_id();
   const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
   const int nAims = X.dirRight ? X.nAncR : X.nAncL;
+  const int ib = X.ia ^ 1;
   int nNew = 0;
   const bool complexIn = ((uint32_t)nCur > P.MAXB);
   for (int base = 0; base < nCur; base += 64) {
     const int tl = base + l;
-    const StepTags mine = probe_and_tag(X, tl, tl < nCur, complexIn);
+    PROF_BEGIN();
+    const StepTags mine = probe_and_tag(tl, tl < nCur, complexIn);
+    PROF_END(PF_PROBE);
     const int cnt = min(64, nCur - base);
     X.steps += (unsigned long long)cnt;
     for (int tt = 0; tt < cnt; ++tt) {
       const int t = base + tt;
       const int tags = __shfl(mine.tags, tt, 64);
+      // the last successor of this Trail inherits its sequence buffer
+      const int lastI = last_successor(tags);
+      if (lastI < 0) pool_free(tr_buf(X.ia, t));   // no successor: the Trail just ends
       for (int i = 0; i < 4; ++i) {
         const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
         if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
@@ -764,37 +929,51 @@ TALC_D int step_bridge(Wv& X, int nCur, int len, uint32_t& stepCounter) {
         const double dd = shfl_f64(mine.dist[i], tt);
         if (nNew >= TCAP) { X.overflow |= OVF_TRAILS; continue; }
         if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
-        make_child(X, t, nNew, i, len, nc, dd);
+        PROF_BEGIN();
+        uint64_t km2, nm2;
+        make_child(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
+        PROF_END(PF_CHILD);
         // checkAims (Trail.cpp:273-285): first aim whose k-mer equals the child's tip
         int hit = -1;
+        PROF_BEGIN();
         {
-          const uint64_t km = X.B.kmer[nNew], nm = X.B.nmask[nNew];
-          for (int ab = 0; ab < nAims && hit < 0; ab += 64) {
+          const int nl = min(nAims, AIMS_LDS);
+          const bool eq0 = (l < nl) && (g_aimK[l] == km2) && (g_aimN[l] == nm2);
+          const unsigned long long m0 = ballot64(eq0);
+          if (m0) hit = (int)__ffsll((long long)m0) - 1;
+          for (int ab = AIMS_LDS; ab < nAims && hit < 0; ab += 64) {
             const int a = ab + l;
-            const bool eq = (a < nAims) && (aims[a].kmer == km) && (aims[a].nmask == nm);
+            const bool eq = (a < nAims) && (aims[a].kmer == km2) && (aims[a].nmask == nm2);
             const unsigned long long m = ballot64(eq);
             if (m) hit = ab + (int)__ffsll((long long)m) - 1;
           }
         }
+        PROF_END(PF_AIMS);
         if (hit >= 0) {
-          const int apos = (int)aims[hit].pos;
-          if (l == 0) { if (X.dirRight) X.B.ranc[nNew] = apos; else X.B.lanc[nNew] = apos; }
-          WSYNC();
+          const int apos = (hit < AIMS_LDS) ? (int)g_aimPos[hit] : (int)aims[hit].pos;
+          TrailRec ch = tr_get(ib, nNew);
+          if (X.dirRight) ch.ranc = apos; else ch.lanc = apos;
+          if (l == 0) tr_put(ib, nNew, ch);
+          WSYNC();   // also publishes the base lane 0 has just appended
           // recordBridge (Explorer.cpp:1097-1101)
           const uint32_t clen = (uint32_t)len + 1;
           if (X.nFull >= (int)X.C.fullCap) X.overflow |= OVF_FULLPATHS;
           else if (X.fullUsed + clen > X.C.fullPool) X.overflow |= OVF_FULLPOOL;
           else {
-            wave_copy_bytes(X.fullPool + X.fullUsed, X.B.seq + (uint64_t)nNew * X.C.seqCap, clen, false);
-            if (l == 0) X.fullMeta[X.nFull] = FullMeta{X.fullUsed, clen, X.B.lanc[nNew], X.B.ranc[nNew], X.B.dist[nNew] / ((double)clen + 0.01)};
+            wave_copy_bytes(X.fullPool + X.fullUsed, X.seqPool + (uint64_t)ch.buf * X.C.seqCap, clen, false);
+            if (l == 0) X.fullMeta[X.nFull] = FullMeta{X.fullUsed, clen, ch.lanc, ch.ranc, ch.dist / ((double)clen + 0.01)};
             X.fullUsed += (clen + 15u) & ~15u;
             X.nFull++;
             WSYNC();
           }
-          if (clen > X.refLen) continue;   // :579-582 pop_back
+          bloom_query_insert(km2, nm2);   // keep the filter a superset of every live Trail's k-mers
+          if (clen > X.refLen) { pool_free(ch.buf); continue; }   // :579-582 pop_back
           ++nNew;
         } else {
-          if (is_cycle(X, t, nNew, len)) continue;   // :586-587 pop_back
+          PROF_BEGIN();
+          const bool cyc = is_cycle(t, nNew, len, km2, nm2);
+          PROF_END(PF_CYCLE);
+          if (cyc) { pool_free(tr_buf(ib, nNew)); continue; }   // :586-587 pop_back
           ++nNew;
         }
       }
@@ -807,35 +986,42 @@ TALC_D int step_bridge(Wv& X, int nCur, int len, uint32_t& stepCounter) {
     // scoreBridges (Explorer.cpp:689-706): reference truncated to K+step+WINDOW (growth-order prefix)
     const uint32_t bound = P.K + stepCounter + P.WINDOW;
     const int tlen = (int)min(bound, X.refLen);
+    PROF_BEGIN();
+    WSYNC();
     for (int j = 0; j < nNew; ++j) {
-      const int sc = nw_score(X, X.ref, tlen, X.B.seq + (uint64_t)j * X.C.seqCap, len + 1, 4, -3, -2, true);
-      if (l == 0) X.B.score[j] = sc;
+      TrailRec r = tr_get(ib, j);
+      r.score = nw_score(X.ref, tlen, X.seqPool + (uint64_t)r.buf * X.C.seqCap, len + 1, 4, -3, -2, true);
+      if (l == 0) tr_put(ib, j, r);
     }
     WSYNC();
+    PROF_END(PF_SCOREBR);
     bool cx = false;
-    nOut = garden(X, nNew, len + 1, cx);
+    PROF_BEGIN();
+    nOut = garden(nNew, len + 1, cx);
+    PROF_END(PF_GARDEN);
     X.complexRegion |= cx;
   } else {
-    swap_sets(X);
+    swap_sets();
     nOut = nNew;
   }
   return nOut;
 }
 
-// Explorer::scoreEdges (Explorer.cpp:709-740) on set B (n trails of length len); survivors are
-// compacted in place (set B); returns their number
-TALC_D int score_edges(Wv& X, int n, int len, int& xdrop) {
+// Explorer::scoreEdges (Explorer.cpp:709-740) on the new set (n trails of length len); survivors
+// are compacted in place; returns their number
+TALC_DN int score_edges(int n, int len, int& xdrop) {
   if (n == 0) return 0;
   const int l = lane_id();
+  const int ib = X.ia ^ 1;
   xdrop += 2;
   int new_xdrop = 0;
   int nSel = 0;
   // trash paths are only needed when nobody survives: remember them by flag in gKept
   for (int t = 0; t < n; ++t) {
-    const bool ok = trail_seed_and_extend(X, X.B, t, len, xdrop);
+    const bool ok = trail_seed_and_extend(ib, t, len, xdrop);
     if (l == 0) X.gKept[t] = ok ? 1u : 0u;
     if (ok) {
-      const int current_xdrop = (int)((double)X.B.score[t] * (-1));
+      const int current_xdrop = (int)((double)tr_get(ib, t).score * (-1));
       if ((new_xdrop > current_xdrop) || (new_xdrop == 0)) new_xdrop = current_xdrop;
       ++nSel;
     }
@@ -843,22 +1029,23 @@ TALC_D int score_edges(Wv& X, int n, int len, int& xdrop) {
   WSYNC();
   xdrop = new_xdrop;
   if (nSel == 0) {
-    for (int t = 0; t < n; ++t) record_edge(X, X.B, t, len);
+    for (int t = 0; t < n; ++t) { record_edge(ib, t, len); pool_free(tr_buf(ib, t)); }
     return 0;
   }
-  // compact survivors to the front of set B, keeping their order
+  // compact survivors to the front, keeping their order (metadata only: the sequence buffers stay
+  // where they are); the buffers of the trashed Trails go back to the pool
   int w = 0;
   for (int t = 0; t < n; ++t) {
     if (X.gKept[t]) {
       if (w != t) {
-        wave_copy(X.B.seq + (uint64_t)w * X.C.seqCap, X.B.seq + (uint64_t)t * X.C.seqCap, (uint32_t)len);
-        if (l == 0) {
-          X.B.kmer[w] = X.B.kmer[t]; X.B.nmask[w] = X.B.nmask[t]; X.B.cnt[w] = X.B.cnt[t]; X.B.score[w] = X.B.score[t];
-          X.B.fail[w] = X.B.fail[t]; X.B.dist[w] = X.B.dist[t]; X.B.lanc[w] = X.B.lanc[t]; X.B.ranc[w] = X.B.ranc[t];
-        }
+        const TrailRec r = tr_get(ib, t);
+        WSYNC();
+        if (l == 0) tr_put(ib, w, r);
         WSYNC();
       }
       ++w;
+    } else {
+      pool_free(tr_buf(ib, t));
     }
   }
   WSYNC();
@@ -866,20 +1053,25 @@ TALC_D int score_edges(Wv& X, int n, int len, int& xdrop) {
 }
 
 // Explorer::oneMoreStepInTheDark (Explorer.cpp:615-687)
-TALC_D int step_edge(Wv& X, int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, int& xdrop) {
+TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, int& xdrop) {
+  PROF_DECL;
   const DevParams& P = X.P;
   const int l = lane_id();
+  const int ib = X.ia ^ 1;
   int nNew = 0;
   const bool complexIn = (nCur > 7);   // :634 hard-coded
   for (int base = 0; base < nCur; base += 64) {
     const int tl = base + l;
-    const StepTags mine = probe_and_tag(X, tl, tl < nCur, complexIn);
+    PROF_BEGIN();
+    const StepTags mine = probe_and_tag(tl, tl < nCur, complexIn);
+    PROF_END(PF_PROBE);
     const int cnt = min(64, nCur - base);
     X.steps += (unsigned long long)cnt;
     for (int tt = 0; tt < cnt; ++tt) {
       const int t = base + tt;
       const int tags = __shfl(mine.tags, tt, 64);
       int counter = 0;
+      const int lastI = last_successor(tags);
       for (int i = 0; i < 4; ++i) {
         const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
         if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
@@ -888,49 +1080,65 @@ TALC_D int step_edge(Wv& X, int nCur, int len, uint32_t& stepCounter, uint32_t P
         const double dd = shfl_f64(mine.dist[i], tt);
         if (nNew >= TCAP) { X.overflow |= OVF_TRAILS; continue; }
         if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
-        make_child(X, t, nNew, i, len, nc, dd);
-        const bool cycle = is_cycle(X, t, nNew, len);
+        PROF_BEGIN();
+        uint64_t km2, nm2;
+        make_child(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
+        PROF_END(PF_CHILD);
+        PROF_BEGIN();
+        const bool cycle = is_cycle(t, nNew, len, km2, nm2);
+        PROF_END(PF_CYCLE);
         if (cycle || (stepCounter + 1 > PATH_MAXLENGTH)) {
-          trail_seed_and_extend(X, X.B, nNew, len + 1, xdrop);
-          record_edge(X, X.B, nNew, len + 1);
+          trail_seed_and_extend(ib, nNew, len + 1, xdrop);
+          record_edge(ib, nNew, len + 1);
+          pool_free(tr_buf(ib, nNew));
           continue;   // pop_back
         }
         ++nNew;
       }
       if (counter == 0) {   // dead end (:657-662)
-        trail_seed_and_extend(X, X.A, t, len, xdrop);
-        record_edge(X, X.A, t, len);
+        trail_seed_and_extend(X.ia, t, len, xdrop);
+        record_edge(X.ia, t, len);
+        pool_free(tr_buf(X.ia, t));
       }
     }
   }
   ++stepCounter;
   int nOut;
   if ((stepCounter % P.CHECK_INTERVAL == 0) || ((uint32_t)nNew >= P.MAX_BORDER_PATHS)) {
-    nNew = score_edges(X, nNew, len + 1, xdrop);
+    nNew = score_edges(nNew, len + 1, xdrop);
     if (nNew > 5) {
       bool cx = false;
-      nOut = garden(X, nNew, len + 1, cx);
+      PROF_BEGIN();
+      nOut = garden(nNew, len + 1, cx);
+      PROF_END(PF_GARDEN);
       X.complexRegion |= cx;
-    } else { swap_sets(X); nOut = nNew; }
-  } else { swap_sets(X); nOut = nNew; }
+    } else { swap_sets(); nOut = nNew; }
+  } else { swap_sets(); nOut = nNew; }
   return nOut;
 }
 
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
-TALC_D void init_first_trail(Wv& X, const AnchorRec& a) {
+TALC_D void init_first_trail(const AnchorRec& a) {
   const int K = (int)X.P.K;
-  wave_copy_bytes(X.A.seq, X.read + a.pos, (uint32_t)K, !X.dirRight);
+  pool_reset();
+  const uint32_t b0 = (uint32_t)pool_alloc();
+  wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
+  g_bloom[lane_id()] = 0ull;
+  LSYNC();
+  bloom_query_insert(a.kmer, a.nmask);
   if (lane_id() == 0) {
-    X.A.kmer[0] = a.kmer; X.A.nmask[0] = a.nmask; X.A.cnt[0] = X.cov[a.pos].x; X.A.score[0] = 0; X.A.fail[0] = 0;
-    X.A.dist[0] = 0.0;
-    X.A.lanc[0] = X.dirRight ? (int)a.pos : -1;
-    X.A.ranc[0] = X.dirRight ? -1 : (int)a.pos;
+    TrailRec r;
+    r.kmer = a.kmer; r.nmask = a.nmask; r.cnt = COVX(a.pos); r.score = 0; r.fail = 0; r.dist = 0.0;
+    r.lanc = X.dirRight ? (int)a.pos : -1;
+    r.ranc = X.dirRight ? -1 : (int)a.pos;
+    r.buf = b0;
+    tr_put(X.ia, 0, r);
   }
   WSYNC();
 }
 
 // append read[from, to) to the reference buffer in growth order
-TALC_D void ref_append(Wv& X, uint32_t from, uint32_t to) {
+TALC_D void ref_append(uint32_t from, uint32_t to) {
   if (to <= from) return;
   const uint32_t n = to - from;
   if (X.refLen + n > X.C.refCap) { X.overflow |= OVF_SEQ; return; }
@@ -941,7 +1149,8 @@ TALC_D void ref_append(Wv& X, uint32_t from, uint32_t to) {
 struct GapResult { bool found; uint32_t Le, Rs; uint32_t wOff, wLen; };
 
 // Explorer::searchBridge (Explorer.cpp:868-989) after initializeINNER(…, direction)
-TALC_D bool search_bridge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+  PROF_DECL;
   const DevParams& P = X.P;
   const uint32_t K = P.K;
   const int l = lane_id();
@@ -949,6 +1158,12 @@ TALC_D bool search_bridge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uin
   const int nAnch = X.dirRight ? X.nAncL : X.nAncR;
   const int limit = min(nAnch, (int)P.MAX_START_ANCHORS);
   bool found = false;
+  {  // the target anchors ("aims") go to LDS for the per-child aim check
+    const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
+    const int nAims = X.dirRight ? X.nAncR : X.nAncL;
+    if (l < min(nAims, AIMS_LDS)) { g_aimK[l] = aims[l].kmer; g_aimN[l] = aims[l].nmask; g_aimPos[l] = aims[l].pos; }
+    LSYNC();
+  }
   for (int s = 0; s < limit && !found; ++s) {
     const AnchorRec a = anchors[s];
     const uint32_t whichStart = a.pos;
@@ -958,25 +1173,25 @@ TALC_D bool search_bridge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uin
     uint32_t gapLen = 0;
     X.refLen = 0;
     if (X.dirRight) {
-      ref_append(X, whichStart, whichStart + K);
-      if (whichStart + K < X.Rs) { gapLen = X.Rs - (whichStart + K); ref_append(X, whichStart + K, X.Rs); }
-      ref_append(X, X.Rs, X.Re + K);
+      ref_append(whichStart, whichStart + K);
+      if (whichStart + K < X.Rs) { gapLen = X.Rs - (whichStart + K); ref_append(whichStart + K, X.Rs); }
+      ref_append(X.Rs, X.Re + K);
     } else {
-      ref_append(X, whichStart, whichStart + K);
-      if (X.Le + K < whichStart) { gapLen = whichStart - (X.Le + K); ref_append(X, X.Le + K, whichStart); }
-      ref_append(X, X.Ls, X.Le + K);
+      ref_append(whichStart, whichStart + K);
+      if (X.Le + K < whichStart) { gapLen = whichStart - (X.Le + K); ref_append(X.Le + K, whichStart); }
+      ref_append(X.Ls, X.Le + K);
       // growth order walking LEFT = reversed text: anchor, then gap, then target, each reversed,
       // which is exactly the reverse of target+gap+anchor (:934-936)
     }
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
-    init_first_trail(X, a);
+    init_first_trail(a);
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
-      nCur = step_bridge(X, nCur, len, stepCounter);
+      nCur = step_bridge(nCur, len, stepCounter);
       ++len;
-      if (X.tracing && X.trace.steps) trace_rec(X, TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
+      if (X.tracing && X.trace.steps) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
     }
     if (X.overflow) return false;
     if (X.nFull > 0) {
@@ -985,13 +1200,14 @@ TALC_D bool search_bridge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uin
       const uint32_t limit2 = X.Re;
       // per full path: score (edit distance), idscore, ok, new right anchor, cut (off,len)
       // stored in gScores (score), gDists (idscore) and gKept (ok | cutLen<<1), ranc updated in meta
+      PROF_BEGIN();
       for (int t = 0; t < X.nFull; ++t) {
         const FullMeta fm = X.fullMeta[t];
         const uint8_t* ps = X.fullPool + fm.off;
         double score, idv;
         // computeEditDistance / computeIDScore (Trajectory.cpp:386-428, 337-384): both non-empty here
-        score = (double)nw_score(X, X.ref, (int)X.refLen, ps, (int)fm.len, 0, -1, -1, false);
-        const int lcs = nw_score(X, X.ref, (int)X.refLen, ps, (int)fm.len, 1, 0, 0, false);
+        score = (double)nw_score(X.ref, (int)X.refLen, ps, (int)fm.len, 0, -1, -1, false);
+        const int lcs = nw_score(X.ref, (int)X.refLen, ps, (int)fm.len, 1, 0, 0, false);
         idv = (double)lcs / (double)max(X.refLen, fm.len);
         // cutAnchors INNER (Trajectory.cpp:176-197)
         bool ok = true;
@@ -1009,6 +1225,7 @@ TALC_D bool search_bridge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uin
         nOK += ok ? 1 : 0;
       }
       WSYNC();
+      PROF_END(PF_EVALFULL);
       const int nCand = (nOK == X.nFull) ? X.nFull : nOK;   // :955-960
       if (nCand > 0) {
         // findBestBridge (Trajectory.cpp:282-303)
@@ -1040,13 +1257,13 @@ TALC_D bool search_bridge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uin
 }
 
 // Explorer::searchEdge (Explorer.cpp:992-1081) after initializeHEAD / initializeTAIL
-TALC_D bool search_edge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
   const DevParams& P = X.P;
   const uint32_t K = P.K;
   const AnchorRec* anchors = X.dirRight ? X.ancL : X.ancR;
   const int nAnch = X.dirRight ? X.nAncL : X.nAncR;
   const int limit = min(nAnch, (int)P.MAX_START_ANCHORS);
-  X.bestLong.have = false; X.bestShort.have = false; X.nEdges = 0;
+  X.best2[0].have = false; X.best2[1].have = false; X.nEdges = 0;
   for (int s = 0; s < limit; ++s) {
     const AnchorRec a = anchors[s];
     const uint32_t whichStart = a.pos;
@@ -1057,30 +1274,31 @@ TALC_D bool search_edge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uint3
     X.refLen = 0;
     if (X.dirRight) {   // TAIL: anchor + suffix(seq, whichStart+K)
       gapLen = X.L - (whichStart + K);
-      ref_append(X, whichStart, X.L);
+      ref_append(whichStart, X.L);
     } else {            // HEAD: prefix(seq, whichStart) + anchor
       gapLen = whichStart;
-      ref_append(X, whichStart, whichStart + K);
-      ref_append(X, 0, whichStart);
+      ref_append(whichStart, whichStart + K);
+      ref_append(0, whichStart);
     }
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
-    init_first_trail(X, a);
+    init_first_trail(a);
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
-      nCur = step_edge(X, nCur, len, stepCounter, PATH_MAXLENGTH, xdrop);
+      nCur = step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop);
       ++len;
       if (X.tracing && X.trace.steps)
-        trace_rec(X, TR_STEP, (int)stepCounter, nCur, X.nEdges, xdrop, 0.0, nullptr, 0, false);
+        trace_rec(TR_STEP, (int)stepCounter, nCur, X.nEdges, xdrop, 0.0, nullptr, 0, false);
     }
     if (X.overflow) return false;
   }
   bool found = false;
-  if (X.bestShort.have || X.bestLong.have) {
+  if (X.best2[1].have || X.best2[0].have) {
     // sortOutBestBorder (Explorer.cpp:310-329): any long path beats every short one
-    const EdgeCand& w = X.bestLong.have ? X.bestLong : X.bestShort;
-    const uint8_t* wseq = X.bestLong.have ? X.edgeLong : X.edgeShort;
+    const int wi = X.best2[0].have ? 0 : 1;
+    const EdgeCand w = X.best2[wi];
+    const uint8_t* wseq = (wi == 0) ? X.edgeLong : X.edgeShort;
     const double diff = (double)X.weakLen - (double)w.len;
     double minScore;
     if ((X.weakLen >= 300) || X.complexRegion) minScore = fmax(0.75, P.MIN_BORDER);
@@ -1098,36 +1316,39 @@ TALC_D bool search_edge(Wv& X, uint32_t& weakOutOff, uint32_t& weakOutLen, uint3
   return found;
 }
 
-TALC_D void trace_search(Wv& X) {
+TALC_D void trace_search() {
   if (!X.tracing) return;
   const int locRef = X.location == LOC_HEAD ? 0 : X.location == LOC_INNER ? 1 : 2;   // Location enum of the reference
   const int nL = (X.location == LOC_HEAD) ? 0 : X.nAncL, nR = (X.location == LOC_TAIL) ? 0 : X.nAncR;
-  trace_rec(X, TR_SEARCH, locRef, X.dirRight, nL, nR, 0.0, nullptr, 0, false);
+  trace_rec(TR_SEARCH, locRef, X.dirRight, nL, nR, 0.0, nullptr, 0, false);
   const int K = (int)X.P.K;
-  for (int i = 0; i < nL; ++i) trace_rec(X, TR_ANCHOR, 0, (int)X.ancL[i].pos, (int)X.ancL[i].count, 0, 0.0, X.read + X.ancL[i].pos, K, false);
-  for (int i = 0; i < nR; ++i) trace_rec(X, TR_ANCHOR, 1, (int)X.ancR[i].pos, (int)X.ancR[i].count, 0, 0.0, X.read + X.ancR[i].pos, K, false);
+  for (int i = 0; i < nL; ++i) trace_rec(TR_ANCHOR, 0, (int)X.ancL[i].pos, (int)X.ancL[i].count, 0, 0.0, X.read + X.ancL[i].pos, K, false);
+  for (int i = 0; i < nR; ++i) trace_rec(TR_ANCHOR, 1, (int)X.ancR[i].pos, (int)X.ancR[i].count, 0, 0.0, X.read + X.ancR[i].pos, K, false);
 }
 
-__global__ void __launch_bounds__(64)
+#ifndef TALC_SEARCH_WAVES_PER_SIMD
+#define TALC_SEARCH_WAVES_PER_SIMD 2
+#endif
+__global__ void __launch_bounds__(64, TALC_SEARCH_WAVES_PER_SIMD)
 k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
          const uint64_t* __restrict__ koff, const uint2* __restrict__ covAll, ReadState* __restrict__ state,
          const uint32_t* __restrict__ regions, const uint64_t* __restrict__ regoff, uint8_t* __restrict__ outAll,
          const uint64_t* __restrict__ outoff, const uint32_t* __restrict__ order, uint32_t n_work,
          uint32_t* __restrict__ queue, uint8_t* __restrict__ scratchAll, uint64_t* __restrict__ counters, TraceBuf trace,
          uint32_t traceRead) {
-  __shared__ int s_dp[3 * LDS_DP_CAP];
   __shared__ uint32_t s_next;
   const int l = lane_id();
   uint8_t* slot = scratchAll + (uint64_t)blockIdx.x * C.slotBytes;
-  Wv X;
   X.P = P; X.T = T; X.C = C;
-  X.A = make_set(slot + C.o_setA, slot + C.o_seqA);
-  X.B = make_set(slot + C.o_setB, slot + C.o_seqB);
+  X.G[0] = make_set(slot + C.o_setA);
+  X.G[1] = make_set(slot + C.o_setB);
+  X.ia = 0;
+  X.seqPool = slot + C.o_seqPool;
   X.ref = slot + C.o_ref; X.ancL = (AnchorRec*)(slot + C.o_ancL); X.ancR = (AnchorRec*)(slot + C.o_ancR);
   X.ancPos = (uint32_t*)(slot + C.o_ancPos);
   X.fullMeta = (FullMeta*)(slot + C.o_fullMeta); X.fullPool = slot + C.o_fullPoolB;
   X.edgeLong = slot + C.o_edgeLong; X.edgeShort = slot + C.o_edgeShort; X.edgeTmp = slot + C.o_edgeTmp;
-  X.dpG = (int*)(slot + C.o_dp); X.dpL = s_dp;
+  X.dpG = (int*)(slot + C.o_dp);
   {
     uint8_t* g = slot + C.o_gard;
     X.gScores = (double*)g; g += 8ull * (TCAP + 64);
@@ -1141,6 +1362,10 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.weak = slot + C.o_weak;
   X.trace = trace;
   unsigned long long totCells = 0, totSteps = 0;
+#ifdef TALC_PROF
+  if (l == 0) for (int i = 0; i < PF_N; ++i) g_prof[i] = 0;
+  const unsigned long long _pf_k0 = __builtin_amdgcn_s_memtime();
+#endif
 
   while (true) {
     WSYNC();
@@ -1192,13 +1417,13 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
           X.location = LOC_INNER; X.dirRight = (attempt == 0) ? 1 : 0;
           X.Ls = X.regS[reg]; X.Le = X.regE[reg]; X.Rs = X.regS[reg + 1]; X.Re = X.regE[reg + 1];
           X.weakLen = (X.Rs > X.Le + K) ? (X.Rs - (X.Le + K)) : 0;
-          build_anchors(X, 0);
-          build_anchors(X, 1);
-          trace_search(X);
-          success = search_bridge(X, wo, wl, weakUsed);
+          build_anchors(0);
+          build_anchors(1);
+          trace_search();
+          success = search_bridge(wo, wl, weakUsed);
           if (X.tracing) {
-            if (success) trace_rec(X, TR_RESULT, 1, 1, (int)X.Le, (int)X.Rs, 0.0, X.weak + wo, wl, false);
-            else trace_rec(X, TR_RESULT, 1, 0, (int)X.regE[reg], (int)X.regS[reg + 1], 0.0, X.read + X.regE[reg] + K, X.weakLen, false);
+            if (success) trace_rec(TR_RESULT, 1, 1, (int)X.Le, (int)X.Rs, 0.0, X.weak + wo, wl, false);
+            else trace_rec(TR_RESULT, 1, 0, (int)X.regE[reg], (int)X.regS[reg + 1], 0.0, X.read + X.regE[reg] + K, X.weakLen, false);
           }
         }
         // updateINNER (Read.cpp:294-303)
@@ -1212,12 +1437,12 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         X.Rs = X.regS[0]; X.Re = X.regE[0]; X.Ls = 0; X.Le = 0;
         X.weakLen = X.Rs;
         X.nAncL = 0;
-        build_anchors(X, 1);
-        trace_search(X);
-        headCorr = search_edge(X, headOff, headCLen, weakUsed);
+        build_anchors(1);
+        trace_search();
+        headCorr = search_edge(headOff, headCLen, weakUsed);
         if (X.tracing) {
-          if (headCorr) trace_rec(X, TR_RESULT, 0, 1, 0, (int)X.Rs, 0.0, X.weak + headOff, headCLen, false);
-          else trace_rec(X, TR_RESULT, 0, 0, 0, (int)X.regS[0], 0.0, X.read, X.weakLen, false);
+          if (headCorr) trace_rec(TR_RESULT, 0, 1, 0, (int)X.Rs, 0.0, X.weak + headOff, headCLen, false);
+          else trace_rec(TR_RESULT, 0, 0, 0, (int)X.regS[0], 0.0, X.read, X.weakLen, false);
         }
         WSYNC();
         if (headCorr && l == 0) X.regS[0] = X.Rs;   // updateHEAD (Read.cpp:305-311)
@@ -1229,12 +1454,12 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         X.Ls = X.regS[R - 1]; X.Le = X.regE[R - 1]; X.Rs = 0; X.Re = 0;
         X.weakLen = L - (X.Le + K);
         X.nAncR = 0;
-        build_anchors(X, 0);
-        trace_search(X);
-        tailCorr = search_edge(X, tailOff, tailCLen, weakUsed);
+        build_anchors(0);
+        trace_search();
+        tailCorr = search_edge(tailOff, tailCLen, weakUsed);
         if (X.tracing) {
-          if (tailCorr) trace_rec(X, TR_RESULT, 2, 1, (int)X.Le, 0, 0.0, X.weak + tailOff, tailCLen, false);
-          else trace_rec(X, TR_RESULT, 2, 0, (int)X.regE[R - 1], 0, 0.0, X.read + X.regE[R - 1] + K, X.weakLen, false);
+          if (tailCorr) trace_rec(TR_RESULT, 2, 1, (int)X.Le, 0, 0.0, X.weak + tailOff, tailCLen, false);
+          else trace_rec(TR_RESULT, 2, 0, (int)X.regE[R - 1], 0, 0.0, X.read + X.regE[R - 1] + K, X.weakLen, false);
         }
         WSYNC();
         if (tailCorr && l == 0) X.regE[R - 1] = X.Le;   // updateTAIL (Read.cpp:313-318)
@@ -1291,6 +1516,10 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   if (l == 0) {
     if (totSteps) atomicAdd((unsigned long long*)&counters[0], totSteps);
     if (totCells) atomicAdd((unsigned long long*)&counters[1], totCells);
+#ifdef TALC_PROF
+    g_prof[PF_TOTAL] = __builtin_amdgcn_s_memtime() - _pf_k0;
+    for (int i = 0; i < PF_N; ++i) atomicAdd((unsigned long long*)&counters[2 + i], g_prof[i]);
+#endif
   }
 }
 
@@ -1318,25 +1547,33 @@ __global__ void k_pack(const uint8_t* __restrict__ outAll, const uint64_t* __res
 // mode 2: wave_find_window(a, pattern=b, wantLast=p3)              -> out[0]
 __global__ void __launch_bounds__(64)
 k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, int p1, int p2, int p3, int K,
-          int* dpG, uint32_t dpCap, int* out) {
-  __shared__ int s_dp[3 * LDS_DP_CAP];
-  Wv X;
-  memset(&X, 0, sizeof X);
-  X.P.K = (uint32_t)K;
-  X.C.dpCap = dpCap; X.dpG = dpG; X.dpL = s_dp;
+          int* dpG, uint32_t dpCap, int* out, double alpha, double err, int minc) {
+  if (lane_id() == 0) memset(&g_X, 0, sizeof g_X);
+  WSYNC();
+  X.P.K = (uint32_t)K; X.P.ALPHA = alpha; X.P.ERR = err; X.P.MIN_COUNT = (uint32_t)minc;
+  X.C.dpCap = dpCap; X.dpG = dpG;
   X.dirRight = p1;
   if (mode == 0) {
-    const int r = nw_score(X, a, la, b, lb, p0, p1, p2, p3 != 0);
+    const int r = nw_score(a, la, b, lb, p0, p1, p2, p3 != 0);
     if (lane_id() == 0) { out[0] = r; out[5] = (int)X.overflow; }
   } else if (mode == 1) {
-    const SeedExt e = seed_and_extension(X, a, la, b, lb, p0, true);
+    const SeedExt e = seed_and_extension(a, la, b, lb, p0, true);
     if (lane_id() == 0) { out[0] = e.lenRefExt; out[1] = e.lenHistExt; out[2] = e.posOnRef; out[3] = e.score; out[4] = e.stop ? 1 : 0; out[5] = (int)X.overflow; }
-  } else {
+  } else if (mode == 2) {
     const int r = wave_find_window(a, la, b, lb, p3 != 0);
     if (lane_id() == 0) out[0] = r;
+  } else {
+    // mode 3: tag_next_nodes on the device.  a = 4 counts + 4 colours + count as 9 little-endian u32 (36 bytes),
+    // p0 = complex; out[0..3] = tags, out[4..11] = the 4 distances as raw bits
+    uint32_t w[9];
+    for (int i = 0; i < 9; ++i) w[i] = (uint32_t)a[4 * i] | ((uint32_t)a[4 * i + 1] << 8) | ((uint32_t)a[4 * i + 2] << 16) | ((uint32_t)a[4 * i + 3] << 24);
+    int tg[4]; double ds[4];
+    tag_next_nodes(X.P.ALPHA, X.P.ERR, X.P.MIN_COUNT, w, w + 4, w[8], p0 != 0, tg, ds);
+    if (lane_id() == 0) for (int i = 0; i < 4; ++i) { out[i] = tg[i]; long long bits = __double_as_longlong(ds[i]); out[4 + 2 * i] = (int)(bits & 0xffffffffll); out[5 + 2 * i] = (int)(bits >> 32); }
   }
 }
 
+#undef X
 #endif  // __HIPCC__
 
 }  // namespace talc

@@ -53,6 +53,9 @@ TALC_HD bool is_expected_by_last_node(double ALPHA, uint32_t nextc, uint32_t cc)
 enum : int { TAG_EXPECTED = 0, TAG_UNEXPECTED = 1, TAG_BREAKPOINT = 7, TAG_NONE = -1 };
 
 // Returns the number of tags produced (0 when no successor reaches MIN_COUNT, else 4).
+// dist[b] is only computed for successors present in the table (count >= MIN_COUNT): the
+// reference only ever reads it for successors that become Trails (Explorer.cpp:570-574,641-646),
+// and those all have count >= MIN_COUNT.
 TALC_HD int tag_next_nodes(double ALPHA, double ERR, uint32_t MINC, const uint32_t cnt[4], const uint32_t jc[4],
                            uint32_t count, bool complex, int tags[4], double dist[4]) {
   int counter = 0;
@@ -62,8 +65,8 @@ TALC_HD int tag_next_nodes(double ALPHA, double ERR, uint32_t MINC, const uint32
   lambda_noise = (uint32_t)(int)((double)count * ERR);
   for (int b = 0; b < 4; ++b) {
     const uint32_t nextc = cnt[b];
-    dist[b] = fabs((double)count - (double)nextc) / sqrt((double)count);
     if (nextc >= MINC) {
+      dist[b] = fabs((double)count - (double)nextc) / sqrt((double)count);
       if (is_expected_by_model(ALPHA, nextc, count, false) || (counter == 1)) {
         tags[b] = TAG_EXPECTED; ++nbExpected;
       } else if (lambda_noise >= MINC) {

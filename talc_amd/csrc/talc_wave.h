@@ -36,16 +36,18 @@ TALC_D int bcast_i32(int v, int src) { return __shfl(v, src, 64); }
 TALC_D unsigned long long ballot64(bool p) { return __ballot(p); }
 
 // dst[0..n) = src[0..n); both 16-byte aligned, n arbitrary (tail by bytes).
-TALC_D void wave_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
+TALC_D void wave_copy(uint8_t* __restrict__ dst_, const uint8_t* __restrict__ src_, uint32_t n) {
   const int l = lane_id();
   const uint32_t nv = n >> 4;
-  const uint4* s4 = reinterpret_cast<const uint4*>(src);
-  uint4* d4 = reinterpret_cast<uint4*>(dst);
+  gu8 dst = (gu8)dst_; gcu8 src = (gcu8)src_;
+  const v4u32 TALC_AS1* s4 = (const v4u32 TALC_AS1*)src;
+  v4u32 TALC_AS1* d4 = (v4u32 TALC_AS1*)dst;
   for (uint32_t i = l; i < nv; i += 64) d4[i] = s4[i];
   for (uint32_t i = (nv << 4) + l; i < n; i += 64) dst[i] = src[i];
 }
 // unaligned byte copy, optional reversal of the source range: dst[i] = src[rev ? n-1-i : i]
-TALC_D void wave_copy_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, bool rev) {
+TALC_D void wave_copy_bytes(uint8_t* __restrict__ dst_, const uint8_t* __restrict__ src_, uint32_t n, bool rev) {
+  gu8 dst = (gu8)dst_; gcu8 src = (gcu8)src_;
   for (uint32_t i = lane_id(); i < n; i += 64) dst[i] = rev ? src[n - 1 - i] : src[i];
 }
 
@@ -60,10 +62,11 @@ TALC_D void wave_copy_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict
 // H spans the DP columns, which are dealt to the lanes in blocks of B = ceil(n/64); lane l
 // sweeps row (t - l) at time step t and hands its block's last cell to lane l+1 by shuffle.
 // `row` holds n+1 ints (LDS or global).  Returns D[m][n]; *cells gets += n*m.
-TALC_D int wave_nw(const uint8_t* __restrict__ H, int n, const uint8_t* __restrict__ V, int m, int match, int mismatch,
-                   int gap, bool freeBegin, int* row, unsigned long long* cells) {
+TALC_D int wave_nw(const uint8_t* __restrict__ H_, int n, const uint8_t* __restrict__ V_, int m, int match, int mismatch,
+                   int gap, bool freeBegin, int* row, unsigned long long& cells) {
+  gcu8 H = (gcu8)H_; gcu8 V = (gcu8)V_;
   const int l = lane_id();
-  if (cells) *cells += (unsigned long long)n * (unsigned long long)m;
+  cells += (unsigned long long)n * (unsigned long long)m;
   if (n == 0) return freeBegin ? 0 : m * gap;
   if (m == 0) return freeBegin ? 0 : n * gap;
   const int B = (n + 63) >> 6;
@@ -117,9 +120,10 @@ TALC_D int wave_nw(const uint8_t* __restrict__ H, int n, const uint8_t* __restri
 // whether the seed moves.
 struct XDropBuf { int* d1; int* d2; int* d3; };
 
-TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg, int qlen, const uint8_t* __restrict__ dbSeg, int dlen,
+TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen,
                        int match, int mismatch, int gapCost, int scoreDropOff, XDropBuf buf, int& extCols, int& extRows,
-                       unsigned long long* cells) {
+                       unsigned long long& cells) {
+  gcu8 querySeg = (gcu8)querySeg_; gcu8 dbSeg = (gcu8)dbSeg_;
   const int l = lane_id();
   const int cols = qlen + 1, rows = dlen + 1;
   extCols = extRows = 0;
@@ -180,7 +184,7 @@ TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg, int qlen, const uin
     maxCol = min(maxCol, cols);
     WSYNC();  // the scans above must finish before lane 0 overwrites antiDiag1 (next antiDiag3)
   }
-  if (cells) *cells += ncell;
+  cells += ncell;
   // longest extension
   int longestExtensionCol = len3 + offset3 - 2;
   int longestExtensionRow = antiDiagNo - longestExtensionCol;
@@ -211,29 +215,189 @@ TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg, int qlen, const uin
   return false;
 }
 
+// ------------------------------------------------------------------ register-blocked NW (n <= 64*NB)
+// Same recurrence and hand-off as wave_nw, but each lane keeps its block of the previous row and
+// its H bases in registers (no LDS / memory traffic inside the sweep) and prefetches the V base
+// of the next step.
+template <int NB>
+TALC_D int wave_nw_reg(const uint8_t* __restrict__ H_, int n, const uint8_t* __restrict__ V_, int m, int match, int mismatch,
+                       int gap, bool freeBegin, unsigned long long& cells) {
+  gcu8 H = (gcu8)H_; gcu8 V = (gcu8)V_;
+  const int l = lane_id();
+  cells += (unsigned long long)n * (unsigned long long)m;
+  if (n == 0) return freeBegin ? 0 : m * gap;
+  if (m == 0) return freeBegin ? 0 : n * gap;
+  const int B = (n + 63) >> 6;
+  const int nl = (n + B - 1) / B;
+  const int j0 = l * B + 1;
+  const int nOwn = max(0, min(B, n - j0 + 1));
+  int h[NB], r[NB];
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) {
+    const int j = j0 + jj;
+    h[jj] = (jj < nOwn) ? (int)H[j - 1] : 255;
+    r[jj] = freeBegin ? 0 : j * gap;
+  }
+  int lastOut = freeBegin ? 0 : (j0 + nOwn - 1) * gap;   // row 0 of the last own column
+  int prevLastOut = lastOut;
+  const int T = m + nl - 1;
+  int vcur = (l == 0) ? (int)V[0] : 0;
+  for (int t = 1; t <= T; ++t) {
+    int vnext = 0;
+    { const int idx = t - l; if (idx >= 0 && idx < m) vnext = (int)V[idx]; }
+    const int nbLast = __shfl_up(lastOut, 1, 64);
+    const int nbPrev = __shfl_up(prevLastOut, 1, 64);
+    const int i = t - l;
+    if (l < nl && i >= 1 && i <= m) {
+      int left, diag;
+      if (l == 0) { left = freeBegin ? 0 : i * gap; diag = freeBegin ? 0 : (i - 1) * gap; }
+      else { left = nbLast; diag = nbPrev; }
+      int v = left;
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) {
+        if (jj < nOwn) {
+          const int up = r[jj];
+          const int d = diag + ((h[jj] == vcur) ? match : mismatch);
+          v = max(d, max(up + gap, left + gap));
+          r[jj] = v;
+          diag = up;
+          left = v;
+        }
+      }
+      prevLastOut = diag;
+      lastOut = v;
+    }
+    vcur = vnext;
+  }
+  // D[m][n] sits in the lane that owns column n
+  const int ln = (n - 1) / B, tj = (n - 1) - ln * B;
+  int res = 0;
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) if (jj == tj) res = r[jj];
+  return __shfl(res, ln, 64);
+}
+
+// ------------------------------------------------------------------ x-drop, band held in registers
+// Same algorithm as wave_xdrop, for live bands of at most 64 cells: the three anti-diagonals live
+// in one register each (lane = column mod 64), neighbours come by lane rotation, the band trimming
+// by ballot + bit scans; no LDS traffic and no barrier inside the loop.  The two segments are
+// staged into `stage` (LDS) when they fit.  Returns 1 if the seed moves, 0 if not, -1 if the band
+// outgrew 64 cells (the caller then uses wave_xdrop).
+TALC_D unsigned long long rot_to_idx(unsigned long long mask, int off) {
+  const int s = off & 63;
+  return s ? ((mask >> s) | (mask << (64 - s))) : mask;
+}
+TALC_D int wave_xdrop_reg(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int match,
+                          int mismatch, int gapCost, int scoreDropOff, uint8_t TALC_AS3* stage, int stageCap, int& extCols,
+                          int& extRows, unsigned long long& cells) {
+  gcu8 querySeg = (gcu8)querySeg_; gcu8 dbSeg = (gcu8)dbSeg_;
+  const int l = lane_id();
+  const int cols = qlen + 1, rows = dlen + 1;
+  extCols = extRows = 0;
+  if (rows == 1 || cols == 1) return 0;
+  const int undef = INT_MIN - gapCost;
+  if (qlen + dlen + 16 > stageCap) return -1;   // segments do not fit the LDS stage: slow path
+  const int qpad = (qlen + 7) & ~7;
+  for (int i = l; i < qlen; i += 64) stage[i] = querySeg[i];
+  for (int i = l; i < dlen; i += 64) stage[qpad + i] = dbSeg[i];
+  WSYNC();
+  const uint8_t TALC_AS3* q = stage;
+  const uint8_t TALC_AS3* d = stage + qpad;
+  const int g0 = (-gapCost > scoreDropOff) ? undef : gapCost;
+  int r1 = undef, r2 = (l == 0) ? 0 : undef, r3 = (l <= 1) ? g0 : undef;   // r2 = [0], r3 = [g,g] before the first rotation
+  int len1 = 0, len2 = 1, len3 = 2, off1 = 0, off2 = 0, off3 = 0;
+  int minCol = 1, maxCol = 2, adn = 1, best = 0;
+  unsigned long long ncell = 0;
+  const int lm1 = (l + 63) & 63;
+  while (minCol < maxCol) {
+    ++adn;
+    r1 = r2; r2 = r3;
+    len1 = len2; len2 = len3;
+    off1 = off2; off2 = off3; off3 = minCol - 1;
+    len3 = maxCol + 1 - off3;
+    if (len3 > 64) return -1;
+    const int idx = (l - off3) & 63;
+    const int col = off3 + idx;
+    const int minScore = best - scoreDropOff;
+    const int left2 = __shfl(r2, lm1, 64);   // antiDiag2[col-1]
+    const int diag1 = __shfl(r1, lm1, 64);   // antiDiag1[col-1]
+    const int own2 = r2;                     // antiDiag2[col]
+    const int border = adn * gapCost;
+    int nv = undef, cand = INT_MIN;
+    if (idx == 0) nv = (off3 == 0 && border > minScore) ? border : undef;
+    else if (idx == len3 - 1) nv = (adn == maxCol && border > minScore) ? border : undef;
+    else if (idx < len3 - 1) {
+      int tmp = max(left2, own2) + gapCost;
+      const int sc = (q[col - 1] == d[adn - col - 1]) ? match : mismatch;
+      tmp = max(tmp, diag1 + sc);
+      if (!(tmp < minScore)) { nv = tmp; cand = tmp; }
+    }
+    r3 = nv;
+    ncell += (unsigned long long)(maxCol - minCol);
+    // with match <= 0 no cell can exceed the initial best (0): the reduction is only needed otherwise
+    if (match > 0) best = max(best, max(border, wave_max_i32(cand)));
+    // band trimming (idx order = column order)
+    const bool pm = (idx >= 1) && (idx < len3) && (nv == undef) && (col - off2 - 1 < len2) && (left2 == undef);
+    const unsigned long long rm = rot_to_idx(ballot64(pm), off3) >> 1;
+    minCol += (int)__ffsll((long long)~rm) - 1;          // consecutive undefined cells from idx 1 upwards
+    const int top = len3 - 2;
+    const bool pM = (idx <= top) && (nv == undef) && (own2 == undef);
+    const unsigned long long rM = ~(rot_to_idx(ballot64(pM), off3) << (63 - top));
+    const int t2 = rM ? (int)__clzll((long long)rM) : 64;   // consecutive undefined cells from idx top downwards
+    maxCol -= min(t2, top + 1);
+    ++maxCol;
+    minCol = max(minCol, adn + 2 - rows);
+    maxCol = min(maxCol, cols);
+  }
+  cells += ncell;
+  int lcol = len3 + off3 - 2;
+  int lrow = adn - lcol;
+  int lscore = __shfl(r3, lcol & 63, 64);
+  if (lscore == undef) {
+    const int a = __shfl(r2, (off2 + len2 - 2) & 63, 64);
+    if (a != undef) { lcol = len2 + off2 - 2; lrow = adn - 1 - lcol; lscore = a; }
+    else if (len2 > 2) {
+      const int b = __shfl(r2, (off2 + len2 - 3) & 63, 64);
+      if (b != undef) { lcol = len2 + off2 - 3; lrow = adn - 1 - lcol; lscore = b; }
+    }
+  }
+  if (lscore == undef) {
+    const int idx1 = (l - off1) & 63;
+    const int v = (idx1 < len1) ? r1 : INT_MIN;
+    const int mx = wave_max_i32(v);
+    if (mx > undef) {
+      const unsigned long long mk = rot_to_idx(ballot64((idx1 < len1) && (r1 == mx)), off1);
+      const int i = (int)__ffsll((long long)mk) - 1;
+      lscore = mx; lcol = i + off1; lrow = adn - 2 - lcol;
+    }
+  }
+  if (lscore != undef) { extCols = lcol; extRows = lrow; return 1; }
+  return 0;
+}
+
 // ------------------------------------------------------------------ k-mer window search
 // Occurrences of pat[0..K) in seq[0..len): returns the first (wantLast=false) or the last
 // (wantLast=true) start index, or -1.  Replaces Finder/Pattern<Horspool> (Trail.cpp:295-298).
-TALC_D int wave_find_window(const uint8_t* __restrict__ seq, int len, const uint8_t* __restrict__ pat, int K, bool wantLast) {
+TALC_D uint64_t load_u64_unaligned(gcu8 p) {
+  typedef uint64_t __attribute__((aligned(1))) u64u;
+  return *(const u64u TALC_AS1*)p;
+}
+
+TALC_D int wave_find_window(const uint8_t* __restrict__ seq_, int len, const uint8_t* __restrict__ pat_, int K, bool wantLast) {
+  gcu8 seq = (gcu8)seq_; gcu8 pat = (gcu8)pat_;
   const int l = lane_id();
   const int nwin = len - K + 1;
   if (nwin <= 0) return -1;
-  if (!wantLast) {
-    for (int base = 0; base < nwin; base += 64) {
-      const int q = base + l;
-      bool eq = q < nwin;
-      if (eq) for (int i = 0; i < K; ++i) if (seq[q + i] != pat[i]) { eq = false; break; }
-      const unsigned long long m = ballot64(eq);
-      if (m) return base + (int)__ffsll((long long)m) - 1;
-    }
-    return -1;
-  }
-  for (int base = ((nwin - 1) / 64) * 64; base >= 0; base -= 64) {
+  // K >= 18: the first 8 bytes filter all but ~4^-8 of the windows with one unaligned 8-byte load
+  const uint64_t p8 = load_u64_unaligned(pat);
+  const int nchunk = (nwin + 63) >> 6;
+  for (int c = 0; c < nchunk; ++c) {
+    const int base = wantLast ? (nchunk - 1 - c) * 64 : c * 64;
     const int q = base + l;
-    bool eq = q < nwin;
-    if (eq) for (int i = 0; i < K; ++i) if (seq[q + i] != pat[i]) { eq = false; break; }
+    bool eq = (q < nwin) && (load_u64_unaligned(seq + q) == p8);
+    if (eq) for (int i = 8; i < K; ++i) if (seq[q + i] != pat[i]) { eq = false; break; }
     const unsigned long long m = ballot64(eq);
-    if (m) return base + 63 - (int)__clzll((long long)m);
+    if (m) return wantLast ? base + 63 - (int)__clzll((long long)m) : base + (int)__ffsll((long long)m) - 1;
   }
   return -1;
 }

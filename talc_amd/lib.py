@@ -82,7 +82,8 @@ class Timing(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_build.OUT, "libtalc_hip.so")
+    # TALC_LIB selects another build of the same library (e.g. the -DTALC_PROF diagnostic build)
+    return os.environ.get("TALC_LIB") or os.path.join(_build.OUT, "libtalc_hip.so")
 
 
 def lib():
@@ -246,8 +247,10 @@ class Context:
         return Batch(self, bases, offsets)
 
     def test_dp(self, mode, a, b, p0=0, p1=0, p2=0, p3=0):
-        out = np.zeros(8, dtype=np.int32)
-        _chk(lib().talc_test_dp(self._h, mode, a.encode(), len(a), b.encode(), len(b), p0, p1, p2, p3, out.ctypes.data))
+        out = np.zeros(12, dtype=np.int32)
+        a = a if isinstance(a, bytes) else a.encode()
+        b = b if isinstance(b, bytes) else b.encode()
+        _chk(lib().talc_test_dp(self._h, mode, a, len(a), b, len(b), p0, p1, p2, p3, out.ctypes.data))
         return out
 
     def correct(self, bases, offsets):

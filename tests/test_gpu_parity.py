@@ -158,6 +158,35 @@ def test_device_window_search(gpu_pair):
         assert ctx.test_dp(2, s, pat, p3=1)[0] == s.rfind(pat)
 
 
+def test_device_tag_next_nodes_matches_oracle(gpu_pair):
+    """tagNextNodes (Explorer.cpp:1226-1298) compiled for the device: tags and, for the successors
+    that become Trails, the distance bit patterns (IEEE double sqrt / division on the GPU)."""
+    import ctypes as C
+    import struct
+    rnd = random.Random(11)
+    L = O.lib()
+    ctx = gpu_pair.ctx
+    p = gpu_pair.q
+    for it in range(3000):
+        count = rnd.choice([0, 1, 2, 3, 5, 30, 80, 400, 5000, rnd.randint(0, 100000)])
+
+        def c():
+            return rnd.choice([0, 0, 0, 1, 2, 3, count, max(0, count - rnd.randint(0, 10)), count + rnd.randint(0, 10),
+                               rnd.randint(0, 50), rnd.randint(0, 20000)])
+        cnt = [c(), c(), c(), c()]
+        jc = [rnd.choice([0, 0, 0, 5]) for _ in range(4)]
+        cx = rnd.random() < 0.3
+        got = ctx.test_dp(3, struct.pack("<9I", *cnt, *jc, count), b"", int(cx))
+        cn, jn = np.array(cnt, dtype=np.uint32), np.array(jc, dtype=np.uint32)
+        t2, d2 = np.zeros(4, np.int32), np.zeros(4, np.float64)
+        L.orc_tag_next_nodes(C.byref(p), cn.ctypes.data, jn.ctypes.data, count, int(cx), t2.ctypes.data, d2.ctypes.data)
+        assert [int(x) for x in got[:4]] == t2.tolist(), (cnt, jc, count, cx)
+        for i in range(4):
+            if t2[i] in (0, 7):
+                bits = struct.pack("<ii", int(got[4 + 2 * i]), int(got[5 + 2 * i]))
+                assert bits == struct.pack("<d", d2[i]), (cnt, count, i)
+
+
 # ---------------------------------------------------------------- whole hot path
 def _check(pair, first, n, nthreads=8):
     bases, offs = pair.reads(first, n)
