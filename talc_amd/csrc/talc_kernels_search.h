@@ -424,6 +424,7 @@ TALC_D int* dp_array(int which, int need) {
 #define NW_REG_NB 12
 TALC_DN int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int match, int mismatch, int gap,
                     bool freeBegin) {
+  la = uni(la); lb = uni(lb);
   // the longer sequence spans the lanes (the score is symmetric in its arguments)
   if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
   unsigned long long ncells = 0;
@@ -437,6 +438,21 @@ TALC_DN int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int mat
   const int r = wave_nw(a, la, b, lb, match, mismatch, gap, freeBegin, row, ncells);
   X.cells += ncells;
   return r;
+}
+
+// edit score (globalAlignment 0/-1/-1) and LCS length (localAlignment 1/0/0) of the same pair
+#define NW2_REG_NB 8
+TALC_DN void edit_and_lcs(const uint8_t* a, int la, const uint8_t* b, int lb, int& editScore, int& lcsLen) {
+  la = uni(la); lb = uni(lb);
+  if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
+  if (la <= 64 * NW2_REG_NB) {
+    unsigned long long ncells = 0;
+    wave_edit_lcs_reg<NW2_REG_NB>(a, la, b, lb, editScore, lcsLen, ncells);
+    X.cells += ncells;
+    return;
+  }
+  editScore = nw_score(a, la, b, lb, 0, -1, -1, false);
+  lcsLen = nw_score(a, la, b, lb, 1, 0, 0, false);
 }
 
 // ------------------------------------------------------------------ trace helpers
@@ -641,6 +657,7 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
                                   bool withScore) {
   PROF_DECL;
+  refLen = uni(refLen); candLen = uni(candLen); xdrop = uni(xdrop); ref = uni_ptr(ref); cand = uni_ptr(cand);
   const int K = (int)X.P.K;
   const int S = X.dirRight ? K - 1 : K;
   SeedExt r;
@@ -654,15 +671,26 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
   const int qlen = len2 - S, dlen = len1 - S;
   if (qlen > 0 && dlen > 0) {
     PROF_BEGIN();
+    int ndiag = 0;
     int rc = wave_xdrop_reg(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, (uint8_t TALC_AS3*)g_dp, 3 * LDS_DP_CAP * 4, extCols, extRows,
-                            ncells);
-    if (rc < 0) {   // band wider than a wavefront: LDS / HBM anti-diagonals
+                            ncells, ndiag);
+#ifdef TALC_PROF
+    g_prof[PF_RECBRIDGE] += 1; g_prof[PF_ASSEMBLE] += (unsigned long long)ndiag; g_prof[PF_SCOREBR] += (rc < 0) ? 1 : 0;
+    g_prof[PF_GARDEN] += __builtin_amdgcn_s_memtime() - _pf_t;
+#endif
+    if (rc < 0) {   // band wider than a wavefront (x-drop above ~30): anti-diagonals in LDS, or in HBM when too long
       const int need = qlen + 3;
-      XDropBuf buf;
-      buf.d1 = dp_array(0, need); buf.d2 = dp_array(1, need); buf.d3 = dp_array(2, need);
       extCols = extRows = 0;
-      if (!((uint32_t)need > X.C.dpCap))
-        wave_xdrop(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, ncells);
+      if (need <= LDS_DP_CAP) {
+        XDropBufT<int TALC_AS3*> buf;
+        buf.d1 = (int TALC_AS3*)g_dp; buf.d2 = buf.d1 + LDS_DP_CAP; buf.d3 = buf.d2 + LDS_DP_CAP;
+        wave_xdrop<int TALC_AS3*, true>(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, ncells);
+      } else {
+        XDropBuf buf;
+        buf.d1 = dp_array(0, need); buf.d2 = dp_array(1, need); buf.d3 = dp_array(2, need);
+        if (!((uint32_t)need > X.C.dpCap))
+          wave_xdrop<int*, false>(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, ncells);
+      }
     }
     PROF_END(PF_XDROP);
     X.cells += ncells;
@@ -732,12 +760,13 @@ TALC_DN void record_edge(int set, int t, int len0) {
   // score of the retained extension (Trail.cpp:408-434)
   PROF_BEGIN();
   double score;
-  if (cur.stop) score = (double)cur.score;
-  else score = (double)nw_score(A, cur.lenRefExt, Bq, cur.lenHistExt, 0, -1, -1, false);
-  // computePercentID (Trajectory.cpp:505-528): LCS / max length
   double idscore;
   {
-    const int lcs = nw_score(A, cur.lenRefExt, Bq, cur.lenHistExt, 1, 0, 0, false);
+    // score of the retained extension (Trail.cpp:408-434) and computePercentID (Trajectory.cpp:505-528):
+    // -edit distance and LCS / max length of the same two extensions
+    int es, lcs;
+    edit_and_lcs(A, cur.lenRefExt, Bq, cur.lenHistExt, es, lcs);
+    score = cur.stop ? (double)cur.score : (double)es;
     const double lenMax = (double)max(cur.lenRefExt, cur.lenHistExt);
     idscore = (double)lcs / lenMax;
   }
@@ -805,9 +834,9 @@ TALC_D StepTags probe_and_tag(int t, bool valid, bool complex) {
   for (int b = 0; b < 4; ++b) { r.nc[b] = cnt[b]; r.dist[b] = ds[b]; }
   return r;
 }
-TALC_D double shfl_f64(double v, int src) {
+TALC_D double shfl_f64(double v, int src) {   // src is wave-uniform
   long long x = __double_as_longlong(v);
-  int lo = __shfl((int)(x & 0xffffffffll), src, 64), hi = __shfl((int)(x >> 32), src, 64);
+  int lo = lane_get((int)(x & 0xffffffffll), src), hi = lane_get((int)(x >> 32), src);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
@@ -918,15 +947,20 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
     X.steps += (unsigned long long)cnt;
     for (int tt = 0; tt < cnt; ++tt) {
       const int t = base + tt;
-      const int tags = __shfl(mine.tags, tt, 64);
+      const int tags = lane_get(mine.tags, tt);
+      // this Trail's 4 successor counts / distances, broadcast once (static register indices)
+      const uint32_t pnc0 = (uint32_t)lane_get((int)mine.nc[0], tt), pnc1 = (uint32_t)lane_get((int)mine.nc[1], tt),
+                     pnc2 = (uint32_t)lane_get((int)mine.nc[2], tt), pnc3 = (uint32_t)lane_get((int)mine.nc[3], tt);
+      const double pdd0 = shfl_f64(mine.dist[0], tt), pdd1 = shfl_f64(mine.dist[1], tt), pdd2 = shfl_f64(mine.dist[2], tt),
+                   pdd3 = shfl_f64(mine.dist[3], tt);
       // the last successor of this Trail inherits its sequence buffer
       const int lastI = last_successor(tags);
       if (lastI < 0) pool_free(tr_buf(X.ia, t));   // no successor: the Trail just ends
       for (int i = 0; i < 4; ++i) {
         const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
         if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
-        const uint32_t nc = (uint32_t)__shfl((int)mine.nc[i], tt, 64);
-        const double dd = shfl_f64(mine.dist[i], tt);
+        const uint32_t nc = (i == 0) ? pnc0 : (i == 1) ? pnc1 : (i == 2) ? pnc2 : pnc3;
+        const double dd = (i == 0) ? pdd0 : (i == 1) ? pdd1 : (i == 2) ? pdd2 : pdd3;
         if (nNew >= TCAP) { X.overflow |= OVF_TRAILS; continue; }
         if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
         PROF_BEGIN();
@@ -1069,15 +1103,20 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
     X.steps += (unsigned long long)cnt;
     for (int tt = 0; tt < cnt; ++tt) {
       const int t = base + tt;
-      const int tags = __shfl(mine.tags, tt, 64);
+      const int tags = lane_get(mine.tags, tt);
+      // this Trail's 4 successor counts / distances, broadcast once (static register indices)
+      const uint32_t pnc0 = (uint32_t)lane_get((int)mine.nc[0], tt), pnc1 = (uint32_t)lane_get((int)mine.nc[1], tt),
+                     pnc2 = (uint32_t)lane_get((int)mine.nc[2], tt), pnc3 = (uint32_t)lane_get((int)mine.nc[3], tt);
+      const double pdd0 = shfl_f64(mine.dist[0], tt), pdd1 = shfl_f64(mine.dist[1], tt), pdd2 = shfl_f64(mine.dist[2], tt),
+                   pdd3 = shfl_f64(mine.dist[3], tt);
       int counter = 0;
       const int lastI = last_successor(tags);
       for (int i = 0; i < 4; ++i) {
         const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
         if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
         ++counter;
-        const uint32_t nc = (uint32_t)__shfl((int)mine.nc[i], tt, 64);
-        const double dd = shfl_f64(mine.dist[i], tt);
+        const uint32_t nc = (i == 0) ? pnc0 : (i == 1) ? pnc1 : (i == 2) ? pnc2 : pnc3;
+        const double dd = (i == 0) ? pdd0 : (i == 1) ? pdd1 : (i == 2) ? pdd2 : pdd3;
         if (nNew >= TCAP) { X.overflow |= OVF_TRAILS; continue; }
         if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
         PROF_BEGIN();
@@ -1115,6 +1154,79 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
     } else { swap_sets(); nOut = nNew; }
   } else { swap_sets(); nOut = nNew; }
   return nOut;
+}
+
+// ------------------------------------------------------------------ single-Trail fast-forward
+// The overwhelmingly common state of a search is ONE live Trail whose tip has exactly ONE
+// successor in the table.  For that state oneMoreStep / oneMoreStepInTheDark reduce to: the
+// successor is EXPECTED (counter == 1, Explorer.cpp:1251), the child inherits everything, no aim
+// is hit, no cycle, no scoring is due.  This loop performs exactly those steps with the Trail
+// held in registers, and stops BEFORE committing any step that is not of that kind (several
+// successors, dead end, aim reached, possible cycle, a scoreEdges step, limits): the generic step
+// then redoes that step from the unchanged state.  Returns the number of steps committed.
+TALC_D int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
+  const DevParams& P = X.P;
+  const uint32_t K = P.K;
+  const int l = lane_id();
+  if (X.tracing && X.trace.steps) return 0;
+  TrailRec r = tr_get(X.ia, 0);
+  if (r.nmask) return 0;
+  const uint64_t kmask = (1ULL << (2 * K)) - 1;
+  const uint64_t m1 = (1ULL << (2 * (K - 1))) - 1;
+  const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
+  const int nAims = edge ? 0 : (X.dirRight ? X.nAncR : X.nAncL);
+  const int nl = min(nAims, AIMS_LDS);
+  gu8 seq = (gu8)(X.seqPool + (uint64_t)r.buf * X.C.seqCap);
+  const int dirRight = X.dirRight;
+  int done = 0;
+  while (stepCounter < PATH_MAXLENGTH) {
+    if (edge && ((stepCounter + 1) % P.CHECK_INTERVAL == 0)) break;          // scoreEdges is due after this step
+    if ((uint32_t)(len + 1) > X.C.seqCap) break;
+    // successors of the tip: one bucket
+    BucketRegs b;
+    const bool ok = dirRight ? probe_bucket(X.T.right, X.T.capacity, r.kmer & m1, b) : probe_bucket(X.T.left, X.T.capacity, r.kmer >> 2, b);
+    if (!ok) break;
+    int counter = 0, which = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (b.cnt[i] >= P.MIN_COUNT) { ++counter; which = i; }
+    if (counter != 1) break;
+    const uint32_t nc = (which == 0) ? b.cnt[0] : (which == 1) ? b.cnt[1] : (which == 2) ? b.cnt[2] : b.cnt[3];
+    uint64_t km2;
+    if (dirRight) km2 = ((r.kmer << 2) | (uint64_t)which) & kmask;
+    else km2 = ((uint64_t)which << (2 * (K - 1))) | (r.kmer >> 2);
+    // aim check (bridges): any hit is handled by the generic step
+    if (nAims > 0) {
+      bool hit = ballot64((l < nl) && (g_aimK[l] == km2) && (g_aimN[l] == 0ull)) != 0ull;
+      for (int ab = AIMS_LDS; ab < nAims && !hit; ab += 64) {
+        const int a = ab + l;
+        hit = ballot64((a < nAims) && (aims[a].kmer == km2) && (aims[a].nmask == 0ull)) != 0ull;
+      }
+      if (hit) break;
+    }
+    // cycle prefilter: query without inserting; a possible cycle goes to the generic step
+    const uint64_t h = mix64(km2);
+    const int l1 = (int)(h & 63), b1 = (int)((h >> 6) & 63), l2 = (int)((h >> 12) & 63), b2 = (int)((h >> 18) & 63);
+    const unsigned long long w1 = g_bloom[l1], w2 = g_bloom[l2];
+    const bool maybe = ((w1 >> b1) & 1ull) && ((w2 >> b2) & 1ull);
+    if (maybe && (len > (int)K)) break;
+    // ---- commit the step
+    if (l == 0) {
+      g_bloom[l1] = w1 | (1ull << b1);
+      g_bloom[l2] = (l1 == l2 ? (w1 | (1ull << b1)) : w2) | (1ull << b2);
+      seq[len] = (uint8_t)which;
+    }
+    LSYNC();
+    r.dist = r.dist + fabs((double)r.cnt - (double)nc) / sqrt((double)r.cnt);   // Explorer.cpp:1247, recordDistance
+    r.kmer = km2;
+    r.cnt = nc;
+    ++len; ++stepCounter; ++done;
+  }
+  if (done) {
+    X.steps += (unsigned long long)done;
+    if (l == 0) tr_put(X.ia, 0, r);
+    LSYNC();
+  }
+  return done;
 }
 
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
@@ -1189,6 +1301,7 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
+      if (nCur == 1) { len += fast_forward(len, stepCounter, PATH_MAXLENGTH, false); if (!(stepCounter < PATH_MAXLENGTH)) break; }
       nCur = step_bridge(nCur, len, stepCounter);
       ++len;
       if (X.tracing && X.trace.steps) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
@@ -1206,8 +1319,9 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
         const uint8_t* ps = X.fullPool + fm.off;
         double score, idv;
         // computeEditDistance / computeIDScore (Trajectory.cpp:386-428, 337-384): both non-empty here
-        score = (double)nw_score(X.ref, (int)X.refLen, ps, (int)fm.len, 0, -1, -1, false);
-        const int lcs = nw_score(X.ref, (int)X.refLen, ps, (int)fm.len, 1, 0, 0, false);
+        int es, lcs;
+        edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs);
+        score = (double)es;
         idv = (double)lcs / (double)max(X.refLen, fm.len);
         // cutAnchors INNER (Trajectory.cpp:176-197)
         bool ok = true;
@@ -1286,6 +1400,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
+      if (nCur == 1) { len += fast_forward(len, stepCounter, PATH_MAXLENGTH, true); if (!(stepCounter < PATH_MAXLENGTH)) break; }
       nCur = step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop);
       ++len;
       if (X.tracing && X.trace.steps)
@@ -1327,7 +1442,7 @@ TALC_D void trace_search() {
 }
 
 #ifndef TALC_SEARCH_WAVES_PER_SIMD
-#define TALC_SEARCH_WAVES_PER_SIMD 2
+#define TALC_SEARCH_WAVES_PER_SIMD 4
 #endif
 __global__ void __launch_bounds__(64, TALC_SEARCH_WAVES_PER_SIMD)
 k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,

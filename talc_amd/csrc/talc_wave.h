@@ -33,6 +33,19 @@ TALC_D unsigned long long wave_sum_u64(unsigned long long v) {
   return v;
 }
 TALC_D int bcast_i32(int v, int src) { return __shfl(v, src, 64); }
+// whole-wave lane moves as one DPP VALU op (gfx9 wave_shr:1 / wave_ror:1) instead of ds_bpermute:
+// lane L receives lane L-1's value; lane 0 keeps `self` (shr) or receives lane 63's (ror).
+TALC_D int lane_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
+TALC_D int lane_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C, 0xF, 0xF, false); }
+// value of lane `src` for a wave-uniform src: v_readlane (SGPR result) instead of ds_bpermute
+TALC_D int lane_get(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+// tell the compiler a value is wave-uniform so that everything derived from it runs on the scalar unit
+TALC_D int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> TALC_D T* uni_ptr(T* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
 TALC_D unsigned long long ballot64(bool p) { return __ballot(p); }
 
 // dst[0..n) = src[0..n); both 16-byte aligned, n arbitrary (tail by bytes).
@@ -118,10 +131,17 @@ TALC_D int wave_nw(const uint8_t* __restrict__ H_, int n, const uint8_t* __restr
 // ints); the lanes span the live columns [minCol, maxCol) of the current anti-diagonal.
 // Outputs the "longest extension" (extCols on the query, extRows on the database) and returns
 // whether the seed moves.
-struct XDropBuf { int* d1; int* d2; int* d3; };
+template <class IP> struct XDropBufT { IP d1; IP d2; IP d3; };
+typedef XDropBufT<int*> XDropBuf;
+#ifndef LSYNC
+#define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 
+// IP = int* (HBM arrays, full barrier) or int AS3* (LDS arrays: a wavefront-scope fence orders the wave's own
+// LDS traffic, no vmcnt wait).
+template <class IP, bool LDS>
 TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen,
-                       int match, int mismatch, int gapCost, int scoreDropOff, XDropBuf buf, int& extCols, int& extRows,
+                       int match, int mismatch, int gapCost, int scoreDropOff, XDropBufT<IP> buf, int& extCols, int& extRows,
                        unsigned long long& cells) {
   gcu8 querySeg = (gcu8)querySeg_; gcu8 dbSeg = (gcu8)dbSeg_;
   const int l = lane_id();
@@ -129,7 +149,7 @@ TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg_, int qlen, const ui
   extCols = extRows = 0;
   if (rows == 1 || cols == 1) return false;
   const int undefined = INT_MIN - gapCost;
-  int* antiDiag1 = buf.d1; int* antiDiag2 = buf.d2; int* antiDiag3 = buf.d3;
+  IP antiDiag1 = buf.d1; IP antiDiag2 = buf.d2; IP antiDiag3 = buf.d3;
   int len1 = 0, len2 = 1, len3 = 2;
   int minCol = 1, maxCol = 2;
   int offset1 = 0, offset2 = 0, offset3 = 0;
@@ -138,13 +158,13 @@ TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg_, int qlen, const ui
     if (-gapCost > scoreDropOff) { antiDiag3[0] = undefined; antiDiag3[1] = undefined; }
     else { antiDiag3[0] = gapCost; antiDiag3[1] = gapCost; }
   }
-  WSYNC();
+  if (LDS) LSYNC(); else WSYNC();
   int antiDiagNo = 1;
   int best = 0;
   unsigned long long ncell = 0;
   while (minCol < maxCol) {
     ++antiDiagNo;
-    { int* t = antiDiag1; antiDiag1 = antiDiag2; antiDiag2 = antiDiag3; antiDiag3 = t; }
+    { IP t = antiDiag1; antiDiag1 = antiDiag2; antiDiag2 = antiDiag3; antiDiag3 = t; }
     len1 = len2; len2 = len3;
     offset1 = offset2; offset2 = offset3; offset3 = minCol - 1;
     len3 = maxCol + 1 - offset3;
@@ -171,7 +191,7 @@ TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg_, int qlen, const ui
     ncell += (unsigned long long)(maxCol - minCol);
     antiDiagBest = wave_max_i32(antiDiagBest);
     best = max(best, antiDiagBest);
-    WSYNC();
+    if (LDS) LSYNC(); else WSYNC();
     // new minCol / maxCol: uniform scans from the two ends of the band
     while (minCol - offset3 < len3 && antiDiag3[minCol - offset3] == undefined && minCol - offset2 - 1 < len2 &&
            antiDiag2[minCol - offset2 - 1] == undefined)
@@ -182,7 +202,7 @@ TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg_, int qlen, const ui
     ++maxCol;
     minCol = max(minCol, antiDiagNo + 2 - rows);
     maxCol = min(maxCol, cols);
-    WSYNC();  // the scans above must finish before lane 0 overwrites antiDiag1 (next antiDiag3)
+    if (LDS) LSYNC(); else WSYNC();  // the scans above must finish before lane 0 overwrites antiDiag1 (next antiDiag3)
   }
   cells += ncell;
   // longest extension
@@ -210,7 +230,7 @@ TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg_, int qlen, const ui
       }
     }
   }
-  WSYNC();
+  if (LDS) LSYNC(); else WSYNC();
   if (longestExtensionScore != undefined) { extCols = longestExtensionCol; extRows = longestExtensionRow; return true; }
   return false;
 }
@@ -222,8 +242,9 @@ TALC_D bool wave_xdrop(const uint8_t* __restrict__ querySeg_, int qlen, const ui
 template <int NB>
 TALC_D int wave_nw_reg(const uint8_t* __restrict__ H_, int n, const uint8_t* __restrict__ V_, int m, int match, int mismatch,
                        int gap, bool freeBegin, unsigned long long& cells) {
-  gcu8 H = (gcu8)H_; gcu8 V = (gcu8)V_;
+  gcu8 H = (gcu8)uni_ptr(H_); gcu8 V = (gcu8)uni_ptr(V_);
   const int l = lane_id();
+  n = uni(n); m = uni(m); match = uni(match); mismatch = uni(mismatch); gap = uni(gap);
   cells += (unsigned long long)n * (unsigned long long)m;
   if (n == 0) return freeBegin ? 0 : m * gap;
   if (m == 0) return freeBegin ? 0 : n * gap;
@@ -245,8 +266,8 @@ TALC_D int wave_nw_reg(const uint8_t* __restrict__ H_, int n, const uint8_t* __r
   for (int t = 1; t <= T; ++t) {
     int vnext = 0;
     { const int idx = t - l; if (idx >= 0 && idx < m) vnext = (int)V[idx]; }
-    const int nbLast = __shfl_up(lastOut, 1, 64);
-    const int nbPrev = __shfl_up(prevLastOut, 1, 64);
+    const int nbLast = lane_shr1(lastOut);
+    const int nbPrev = lane_shr1(prevLastOut);
     const int i = t - l;
     if (l < nl && i >= 1 && i <= m) {
       int left, diag;
@@ -274,7 +295,71 @@ TALC_D int wave_nw_reg(const uint8_t* __restrict__ H_, int n, const uint8_t* __r
   int res = 0;
 #pragma unroll
   for (int jj = 0; jj < NB; ++jj) if (jj == tj) res = r[jj];
-  return __shfl(res, ln, 64);
+  return lane_get(res, ln);
+}
+
+// ------------------------------------------------------------------ fused edit distance + LCS (n <= 64*NB)
+// The reference always scores a candidate twice against the same reference: globalAlignment with
+// Score(0,-1,-1) (= -edit distance, Trajectory.cpp:413 / Trail.cpp:422) and localAlignment with
+// Score(1,0,0) (= LCS length, Trajectory.cpp:368,525).  One lane-skewed sweep computes both
+// (shared base loads, shared hand-off structure).
+template <int NB>
+TALC_D void wave_edit_lcs_reg(const uint8_t* __restrict__ H_, int n, const uint8_t* __restrict__ V_, int m, int& editScore,
+                              int& lcsLen, unsigned long long& cells) {
+  gcu8 H = (gcu8)uni_ptr(H_); gcu8 V = (gcu8)uni_ptr(V_);
+  const int l = lane_id();
+  n = uni(n); m = uni(m);
+  cells += 2ull * (unsigned long long)n * (unsigned long long)m;
+  if (n == 0 || m == 0) { editScore = -(n + m); lcsLen = 0; return; }
+  const int B = (n + 63) >> 6;
+  const int nl = (n + B - 1) / B;
+  const int j0 = l * B + 1;
+  const int nOwn = max(0, min(B, n - j0 + 1));
+  int h[NB], re[NB], rl[NB];
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) {
+    const int j = j0 + jj;
+    h[jj] = (jj < nOwn) ? (int)H[j - 1] : 255;
+    re[jj] = -j;
+    rl[jj] = 0;
+  }
+  int lastE = -(j0 + nOwn - 1), prevE = lastE, lastL = 0, prevL = 0;
+  const int T = m + nl - 1;
+  int vcur = (l == 0) ? (int)V[0] : 0;
+  for (int t = 1; t <= T; ++t) {
+    int vnext = 0;
+    { const int idx = t - l; if (idx >= 0 && idx < m) vnext = (int)V[idx]; }
+    const int nbLastE = lane_shr1(lastE), nbPrevE = lane_shr1(prevE);
+    const int nbLastL = lane_shr1(lastL), nbPrevL = lane_shr1(prevL);
+    const int i = t - l;
+    if (l < nl && i >= 1 && i <= m) {
+      int leftE, diagE, leftL, diagL;
+      if (l == 0) { leftE = -i; diagE = -(i - 1); leftL = 0; diagL = 0; }
+      else { leftE = nbLastE; diagE = nbPrevE; leftL = nbLastL; diagL = nbPrevL; }
+      int vE = leftE, vL = leftL;
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) {
+        if (jj < nOwn) {
+          const bool eq = (h[jj] == vcur);
+          const int upE = re[jj], upL = rl[jj];
+          vE = max(diagE + (eq ? 0 : -1), max(upE, leftE) - 1);
+          vL = max(diagL + (eq ? 1 : 0), max(upL, leftL));
+          re[jj] = vE; rl[jj] = vL;
+          diagE = upE; leftE = vE;
+          diagL = upL; leftL = vL;
+        }
+      }
+      prevE = diagE; lastE = vE;
+      prevL = diagL; lastL = vL;
+    }
+    vcur = vnext;
+  }
+  const int ln = (n - 1) / B, tj = (n - 1) - ln * B;
+  int resE = 0, resL = 0;
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) if (jj == tj) { resE = re[jj]; resL = rl[jj]; }
+  editScore = lane_get(resE, ln);
+  lcsLen = lane_get(resL, ln);
 }
 
 // ------------------------------------------------------------------ x-drop, band held in registers
@@ -289,9 +374,10 @@ TALC_D unsigned long long rot_to_idx(unsigned long long mask, int off) {
 }
 TALC_D int wave_xdrop_reg(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int match,
                           int mismatch, int gapCost, int scoreDropOff, uint8_t TALC_AS3* stage, int stageCap, int& extCols,
-                          int& extRows, unsigned long long& cells) {
-  gcu8 querySeg = (gcu8)querySeg_; gcu8 dbSeg = (gcu8)dbSeg_;
+                          int& extRows, unsigned long long& cells, int& ndiag) {
+  gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
+  qlen = uni(qlen); dlen = uni(dlen); scoreDropOff = uni(scoreDropOff); gapCost = uni(gapCost); match = uni(match); mismatch = uni(mismatch);
   const int cols = qlen + 1, rows = dlen + 1;
   extCols = extRows = 0;
   if (rows == 1 || cols == 1) return 0;
@@ -308,7 +394,6 @@ TALC_D int wave_xdrop_reg(const uint8_t* __restrict__ querySeg_, int qlen, const
   int len1 = 0, len2 = 1, len3 = 2, off1 = 0, off2 = 0, off3 = 0;
   int minCol = 1, maxCol = 2, adn = 1, best = 0;
   unsigned long long ncell = 0;
-  const int lm1 = (l + 63) & 63;
   while (minCol < maxCol) {
     ++adn;
     r1 = r2; r2 = r3;
@@ -319,8 +404,8 @@ TALC_D int wave_xdrop_reg(const uint8_t* __restrict__ querySeg_, int qlen, const
     const int idx = (l - off3) & 63;
     const int col = off3 + idx;
     const int minScore = best - scoreDropOff;
-    const int left2 = __shfl(r2, lm1, 64);   // antiDiag2[col-1]
-    const int diag1 = __shfl(r1, lm1, 64);   // antiDiag1[col-1]
+    const int left2 = lane_ror1(r2);   // antiDiag2[col-1]
+    const int diag1 = lane_ror1(r1);   // antiDiag1[col-1]
     const int own2 = r2;                     // antiDiag2[col]
     const int border = adn * gapCost;
     int nv = undef, cand = INT_MIN;
@@ -339,25 +424,26 @@ TALC_D int wave_xdrop_reg(const uint8_t* __restrict__ querySeg_, int qlen, const
     // band trimming (idx order = column order)
     const bool pm = (idx >= 1) && (idx < len3) && (nv == undef) && (col - off2 - 1 < len2) && (left2 == undef);
     const unsigned long long rm = rot_to_idx(ballot64(pm), off3) >> 1;
-    minCol += (int)__ffsll((long long)~rm) - 1;          // consecutive undefined cells from idx 1 upwards
+    minCol += uni((int)__ffsll((long long)~rm) - 1);     // consecutive undefined cells from idx 1 upwards
     const int top = len3 - 2;
     const bool pM = (idx <= top) && (nv == undef) && (own2 == undef);
     const unsigned long long rM = ~(rot_to_idx(ballot64(pM), off3) << (63 - top));
     const int t2 = rM ? (int)__clzll((long long)rM) : 64;   // consecutive undefined cells from idx top downwards
-    maxCol -= min(t2, top + 1);
+    maxCol -= uni(min(t2, top + 1));
     ++maxCol;
     minCol = max(minCol, adn + 2 - rows);
     maxCol = min(maxCol, cols);
   }
   cells += ncell;
+  ndiag = adn;
   int lcol = len3 + off3 - 2;
   int lrow = adn - lcol;
-  int lscore = __shfl(r3, lcol & 63, 64);
+  int lscore = lane_get(r3, lcol & 63);
   if (lscore == undef) {
-    const int a = __shfl(r2, (off2 + len2 - 2) & 63, 64);
+    const int a = lane_get(r2, (off2 + len2 - 2) & 63);
     if (a != undef) { lcol = len2 + off2 - 2; lrow = adn - 1 - lcol; lscore = a; }
     else if (len2 > 2) {
-      const int b = __shfl(r2, (off2 + len2 - 3) & 63, 64);
+      const int b = lane_get(r2, (off2 + len2 - 3) & 63);
       if (b != undef) { lcol = len2 + off2 - 3; lrow = adn - 1 - lcol; lscore = b; }
     }
   }

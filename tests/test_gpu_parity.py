@@ -133,7 +133,8 @@ def test_device_seed_and_extension_matches_oracle(gpu_pair):
         elif rnd.random() < 0.3:
             cand = cand + [rnd.choice("ACGT") for _ in range(rnd.randint(1, 40))]
         ref, cand = "".join(ref), "".join(cand)
-        xdrop = rnd.randint(-1, 30)
+        # <= ~30: band held in registers; above: LDS anti-diagonals (short segments) or HBM ones (long segments)
+        xdrop = rnd.randint(-1, 30) if rnd.random() < 0.6 else rnd.randint(31, 160)
         for direction in (0, 1):
             out = np.zeros(3, dtype=np.int64)
             stop = C.c_int32()
