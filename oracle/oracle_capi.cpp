@@ -236,6 +236,12 @@ void orc_extend_seed(const char* database, const char* query, int64_t* seed4, in
   shim::extendSeed(s, database, query, dir ? shim::EXTEND_RIGHT : shim::EXTEND_LEFT, {match, mismatch, gap}, xdrop);
   seed4[0] = s.beginH; seed4[1] = s.beginV; seed4[2] = s.endH; seed4[3] = s.endV;
 }
+// _extendSeedGappedXDropOneDirection, EXTEND_RIGHT, on whole segments; out4 = moved, extCols, extRows, extScore
+void orc_xdrop_right(const char* query, const char* database, int match, int mismatch, int gap, int xdrop, int32_t* out4) {
+  long ec = 0, er = 0; int es = 0;
+  const bool m = shim::gappedXDropOneDirection(query, database, shim::EXTEND_RIGHT, {match, mismatch, gap}, xdrop, ec, er, es);
+  out4[0] = m ? 1 : 0; out4[1] = (int32_t)ec; out4[2] = (int32_t)er; out4[3] = es;
+}
 // getSeedAndExtension (Trail.cpp:341): out3 = {len(refExtension), len(histExtension), posOnRef}; returns score
 double orc_seed_and_extension(const char* reference, const char* candidate, int xdrop, int direction,
                               uint32_t seedSize, int64_t* out3, int32_t* stopThere) {

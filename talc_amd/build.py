@@ -65,15 +65,21 @@ def build_pure(force=False):
 HIP_SOURCES = ["talc_capi.hip"]
 
 
-def build_hip(force=False, extra_flags=()):
+def build_hip(force=False, extra_flags=(), name="libtalc_hip.so"):
     os.makedirs(OUT, exist_ok=True)
-    tgt = os.path.join(OUT, "libtalc_hip.so")
+    tgt = os.path.join(OUT, name)
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     if force or _newer(tgt, _deps(*HIP_SOURCES)):
         _run([HIPCC, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-shared", "-fopenmp",
               "-ffp-contract=off", "-fgpu-rdc" if False else "-fno-gpu-rdc",
               "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC, *extra_flags, *srcs, "-o", tgt])
     return tgt
+
+
+def build_hip_prof(force=False):
+    """Developer build with the in-kernel s_memtime category profiler (select it with TALC_LIB=..., print
+    with TALC_PROF_PRINT=1); never loaded by default."""
+    return build_hip(force, ("-DTALC_PROF",), "libtalc_hip_prof.so")
 
 
 def build_cli(force=False):
@@ -102,4 +108,7 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--prof" in sys.argv:
+        build_hip_prof(force="--force" in sys.argv)
+    else:
+        build_all(force="--force" in sys.argv)

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "talc_pure.h"
+#include "talc_wfa.h"
 
 using namespace talc;
 
@@ -75,4 +76,9 @@ void pure_sort_anchors(double cc, uint32_t* pos, uint32_t* count, int n) {
   for (int i = 0; i < n; ++i) { pos[i] = a[i].pos; count[i] = a[i].count; }
 }
 
+// wavefront statement of the unit-cost x-drop extension (talc_wfa.h); out4 = moved, extCols, extRows, score
+void pure_wfa_xdrop(const uint8_t* q, int qlen, const uint8_t* d, int dlen, int x, int32_t* out4) {
+  const WfaResult r = wfa_xdrop_scalar(q, qlen, d, dlen, x);
+  out4[0] = r.moved; out4[1] = r.extCols; out4[2] = r.extRows; out4[3] = r.score;
+}
 }  // extern "C"

@@ -666,21 +666,22 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
   const bool state = !(refLen < candLen);
   const uint8_t* seq1 = state ? ref : cand; const int len1 = state ? refLen : candLen;
   const uint8_t* seq2 = state ? cand : ref; const int len2 = state ? candLen : refLen;
-  int extCols = 0, extRows = 0;
+  int extCols = 0, extRows = 0, extScore = 0, rc = 0;
   unsigned long long ncells = 0;
   const int qlen = len2 - S, dlen = len1 - S;
   if (qlen > 0 && dlen > 0) {
     PROF_BEGIN();
-    int ndiag = 0;
-    int rc = wave_xdrop_reg(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, (uint8_t TALC_AS3*)g_dp, 3 * LDS_DP_CAP * 4, extCols, extRows,
-                            ncells, ndiag);
-#ifdef TALC_PROF
-    g_prof[PF_RECBRIDGE] += 1; g_prof[PF_ASSEMBLE] += (unsigned long long)ndiag; g_prof[PF_SCOREBR] += (rc < 0) ? 1 : 0;
-    g_prof[PF_GARDEN] += __builtin_amdgcn_s_memtime() - _pf_t;
-#endif
+    constexpr int STAGE = 3 * LDS_DP_CAP * 4;
+    uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
+    // furthest-reaching wavefronts, 1 / 2 / 4 diagonals per lane (x up to 31 / 63 / 127)
+    const int ndiagonals = min(max(xdrop, 0), qlen) + min(max(xdrop, 0), dlen) + 1;
+    if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (ndiagonals <= 127) rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (ndiagonals <= 255) rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else rc = -1;
     if (rc < 0) {   // band wider than a wavefront (x-drop above ~30): anti-diagonals in LDS, or in HBM when too long
       const int need = qlen + 3;
-      extCols = extRows = 0;
+      extCols = extRows = 0; rc = -1;
       if (need <= LDS_DP_CAP) {
         XDropBufT<int TALC_AS3*> buf;
         buf.d1 = (int TALC_AS3*)g_dp; buf.d2 = buf.d1 + LDS_DP_CAP; buf.d3 = buf.d2 + LDS_DP_CAP;
@@ -702,7 +703,19 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
   r.lenHistExt = S + r.extCand;
   r.posOnRef = X.dirRight ? (S + r.extRef) : (refLen - K - r.extRef);
   if (max(r.lenRefExt, r.lenHistExt) >= K) {
-    if (withScore) { PROF_BEGIN(); r.score = nw_score(ref, r.lenRefExt, cand, r.lenHistExt, 0, -1, -1, false); PROF_END(PF_EXTNW); }
+    // Trail.cpp:408-434 scores the two extensions (anchor included) by a global alignment (0,-1,-1) = minus their edit
+    // distance.  Both start with the same anchor, so that is the edit distance of the extended segments, and the
+    // x-drop value of the cell it stopped on is exactly that (a defined cell holds the best path from the origin;
+    // a path that leaves the x-drop region costs more than x, the cell's own cost is at most x).
+    if (withScore) {
+      bool sameAnchor = false;
+      if (rc == 1) {   // (the reference does not require equal anchors; every caller on the correction path has them)
+        const int l = lane_id();
+        sameAnchor = ballot64(l < S && ((gcu8)ref)[l < S ? l : 0] != ((gcu8)cand)[l < S ? l : 0]) == 0ull;
+      }
+      if (sameAnchor) r.score = extScore;
+      else { PROF_BEGIN(); r.score = nw_score(ref, r.lenRefExt, cand, r.lenHistExt, 0, -1, -1, false); PROF_END(PF_EXTNW); }
+    }
   } else {
     r.score = (-1) * xdrop;
     r.stop = true;

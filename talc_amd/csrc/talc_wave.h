@@ -363,18 +363,32 @@ TALC_D void wave_edit_lcs_reg(const uint8_t* __restrict__ H_, int n, const uint8
 }
 
 // ------------------------------------------------------------------ x-drop, band held in registers
-// Same algorithm as wave_xdrop, for live bands of at most 64 cells: the three anti-diagonals live
-// in one register each (lane = column mod 64), neighbours come by lane rotation, the band trimming
-// by ballot + bit scans; no LDS traffic and no barrier inside the loop.  The two segments are
-// staged into `stage` (LDS) when they fit.  Returns 1 if the seed moves, 0 if not, -1 if the band
-// outgrew 64 cells (the caller then uses wave_xdrop).
+// Same algorithm as wave_xdrop, for live bands of at most 64*NR cells: each of the three
+// anti-diagonals lives in NR registers per lane (ring position = column mod 64*NR; lane = position
+// mod 64, register = position / 64), neighbours come by a one-lane rotation (DPP), the band
+// trimming by ballots + scalar bit scans; the inner computation is branch-free; no memory traffic
+// and no barrier inside the loop.  The two segments are staged into `stage` (LDS).
+// Returns 1 if the seed moves, 0 if not, -1 if the band outgrew 64*NR cells or the segments do not
+// fit the stage (the caller then retries with a larger NR / the array version).
 TALC_D unsigned long long rot_to_idx(unsigned long long mask, int off) {
   const int s = off & 63;
   return s ? ((mask >> s) | (mask << (64 - s))) : mask;
 }
+// bits [from, from+64) (ring order, modulo 64*NR) of the ring bitmap B[NR]
+template <int NR>
+TALC_D unsigned long long ring_word(const unsigned long long (&B)[NR], int from) {
+  const int s = from & 63, w = (from >> 6) % NR, w1 = (w + 1) % NR;
+  unsigned long long lo = B[0], hi = B[0];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) { if (k == w) lo = B[k]; if (k == w1) hi = B[k]; }
+  return s ? ((lo >> s) | (hi << (64 - s))) : lo;
+}
+
+template <int NR>
 TALC_D int wave_xdrop_reg(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int match,
                           int mismatch, int gapCost, int scoreDropOff, uint8_t TALC_AS3* stage, int stageCap, int& extCols,
-                          int& extRows, unsigned long long& cells, int& ndiag) {
+                          int& extRows, unsigned long long& cells, int& ndiag, int& extScore) {
+  constexpr int M = 64 * NR;
   gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
   qlen = uni(qlen); dlen = uni(dlen); scoreDropOff = uni(scoreDropOff); gapCost = uni(gapCost); match = uni(match); mismatch = uni(mismatch);
@@ -390,75 +404,330 @@ TALC_D int wave_xdrop_reg(const uint8_t* __restrict__ querySeg_, int qlen, const
   const uint8_t TALC_AS3* q = stage;
   const uint8_t TALC_AS3* d = stage + qpad;
   const int g0 = (-gapCost > scoreDropOff) ? undef : gapCost;
-  int r1 = undef, r2 = (l == 0) ? 0 : undef, r3 = (l <= 1) ? g0 : undef;   // r2 = [0], r3 = [g,g] before the first rotation
+  int r1[NR], r2[NR], r3[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) { r1[k] = undef; r2[k] = undef; r3[k] = undef; }
+  r2[0] = (l == 0) ? 0 : undef;        // antiDiag2 = [0]      (column 0)
+  r3[0] = (l <= 1) ? g0 : undef;       // antiDiag3 = [g, g]   (columns 0, 1)
   int len1 = 0, len2 = 1, len3 = 2, off1 = 0, off2 = 0, off3 = 0;
   int minCol = 1, maxCol = 2, adn = 1, best = 0;
   unsigned long long ncell = 0;
   while (minCol < maxCol) {
     ++adn;
-    r1 = r2; r2 = r3;
     len1 = len2; len2 = len3;
     off1 = off2; off2 = off3; off3 = minCol - 1;
     len3 = maxCol + 1 - off3;
-    if (len3 > 64) return -1;
-    const int idx = (l - off3) & 63;
-    const int col = off3 + idx;
+    if (len3 > M) return -1;
     const int minScore = best - scoreDropOff;
-    const int left2 = lane_ror1(r2);   // antiDiag2[col-1]
-    const int diag1 = lane_ror1(r1);   // antiDiag1[col-1]
-    const int own2 = r2;                     // antiDiag2[col]
     const int border = adn * gapCost;
-    int nv = undef, cand = INT_MIN;
-    if (idx == 0) nv = (off3 == 0 && border > minScore) ? border : undef;
-    else if (idx == len3 - 1) nv = (adn == maxCol && border > minScore) ? border : undef;
-    else if (idx < len3 - 1) {
-      int tmp = max(left2, own2) + gapCost;
-      const int sc = (q[col - 1] == d[adn - col - 1]) ? match : mismatch;
-      tmp = max(tmp, diag1 + sc);
-      if (!(tmp < minScore)) { nv = tmp; cand = tmp; }
+    const int b0 = (off3 == 0 && border > minScore) ? border : undef;        // first column
+    const int bN = (adn == maxCol && border > minScore) ? border : undef;    // first row
+    int rot2[NR], rot1[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { r1[k] = r2[k]; r2[k] = r3[k]; }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { rot2[k] = lane_ror1(r2[k]); rot1[k] = lane_ror1(r1[k]); }
+    unsigned long long Bm[NR], BM[NR];
+    int cand = INT_MIN;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int kp = (k + NR - 1) % NR;
+      const int left2 = (NR > 1 && l == 0) ? rot2[kp] : rot2[k];   // antiDiag2[col-1]
+      const int diag1 = (NR > 1 && l == 0) ? rot1[kp] : rot1[k];   // antiDiag1[col-1]
+      const int own2 = r2[k];                                      // antiDiag2[col]
+      const int idx = (64 * k + l - off3) & (M - 1);
+      const int col = off3 + idx;
+      const int qi = min(max(col - 1, 0), qlen - 1), di = min(max(adn - col - 1, 0), dlen - 1);
+      const int sc = (q[qi] == d[di]) ? match : mismatch;
+      const int tmp = max(max(left2, own2) + gapCost, diag1 + sc);
+      const bool interior = (idx >= 1) & (idx < len3 - 1);
+      int nv = (interior & (tmp >= minScore)) ? tmp : undef;
+      if (match > 0) cand = max(cand, nv);
+      nv = (idx == 0) ? b0 : nv;
+      nv = (idx == len3 - 1) ? bN : nv;
+      r3[k] = nv;
+      const bool u3 = (nv == undef);
+      Bm[k] = ballot64((idx >= 1) & (idx < len3) & u3 & (col - off2 - 1 < len2) & (left2 == undef));
+      BM[k] = ballot64((idx <= len3 - 2) & u3 & (own2 == undef));
     }
-    r3 = nv;
     ncell += (unsigned long long)(maxCol - minCol);
     // with match <= 0 no cell can exceed the initial best (0): the reduction is only needed otherwise
     if (match > 0) best = max(best, max(border, wave_max_i32(cand)));
-    // band trimming (idx order = column order)
-    const bool pm = (idx >= 1) && (idx < len3) && (nv == undef) && (col - off2 - 1 < len2) && (left2 == undef);
-    const unsigned long long rm = rot_to_idx(ballot64(pm), off3) >> 1;
-    minCol += uni((int)__ffsll((long long)~rm) - 1);     // consecutive undefined cells from idx 1 upwards
-    const int top = len3 - 2;
-    const bool pM = (idx <= top) && (nv == undef) && (own2 == undef);
-    const unsigned long long rM = ~(rot_to_idx(ballot64(pM), off3) << (63 - top));
-    const int t2 = rM ? (int)__clzll((long long)rM) : 64;   // consecutive undefined cells from idx top downwards
-    maxCol -= uni(min(t2, top + 1));
+    // ---- band trimming: count undefined cells from idx 1 upwards / from idx len3-2 downwards
+    int t1 = 0;
+    {
+      int pos = off3 + 1, left = len3;   // at most len3-1 cells can be trimmed, pm is false beyond anyway
+      while (left > 0) {
+        const unsigned long long w = ring_word<NR>(Bm, pos);
+        const int run = (int)__ffsll((long long)~w) - 1;   // 0..64 (ffsll(0) = 0 -> -1 cannot happen: ~w == 0 only if w all ones)
+        const int r = (~w == 0ull) ? 64 : run;
+        t1 += r;
+        if (r < 64) break;
+        pos += 64; left -= 64;
+      }
+    }
+    minCol += uni(t1);
+    int t2 = 0;
+    {
+      const int top = len3 - 2;          // idx of the first candidate, going down to idx 0
+      int hiIdx = top;
+      while (hiIdx >= 0) {
+        // word holding idx (hiIdx-63 .. hiIdx), bit 63 = idx hiIdx
+        const unsigned long long w = ring_word<NR>(BM, off3 + hiIdx - 63 + M);
+        // idx below 0 are not candidates: mask them out (they read as zero = stop)
+        const int valid = min(hiIdx + 1, 64);
+        const unsigned long long wm = (valid == 64) ? w : (w & (~0ull << (64 - valid)));
+        const unsigned long long nw = ~wm;
+        const int run = nw ? (int)__clzll((long long)nw) : 64;
+        t2 += run;
+        if (run < 64) break;
+        hiIdx -= 64;
+      }
+      t2 = min(t2, top + 1);
+    }
+    maxCol -= uni(t2);
     ++maxCol;
     minCol = max(minCol, adn + 2 - rows);
     maxCol = min(maxCol, cols);
   }
   cells += ncell;
   ndiag = adn;
+  // value of antiDiag[col] for a wave-uniform col
+  auto pick = [&](const int (&r)[NR], int col) -> int {
+    const int slot = ((col & (M - 1)) >> 6);
+    int v = r[0];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) if (k == slot) v = r[k];
+    return lane_get(v, col & 63);
+  };
   int lcol = len3 + off3 - 2;
   int lrow = adn - lcol;
-  int lscore = lane_get(r3, lcol & 63);
+  int lscore = pick(r3, lcol);
   if (lscore == undef) {
-    const int a = lane_get(r2, (off2 + len2 - 2) & 63);
+    const int a = pick(r2, off2 + len2 - 2);
     if (a != undef) { lcol = len2 + off2 - 2; lrow = adn - 1 - lcol; lscore = a; }
     else if (len2 > 2) {
-      const int b = lane_get(r2, (off2 + len2 - 3) & 63);
+      const int b = pick(r2, off2 + len2 - 3);
       if (b != undef) { lcol = len2 + off2 - 3; lrow = adn - 1 - lcol; lscore = b; }
     }
   }
   if (lscore == undef) {
-    const int idx1 = (l - off1) & 63;
-    const int v = (idx1 < len1) ? r1 : INT_MIN;
+    // general case: first maximum of antiDiag1
+    int v = INT_MIN;
+    unsigned long long dummy = 0; (void)dummy;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { const int idx1 = (64 * k + l - off1) & (M - 1); if (idx1 < len1) v = max(v, r1[k]); }
     const int mx = wave_max_i32(v);
     if (mx > undef) {
-      const unsigned long long mk = rot_to_idx(ballot64((idx1 < len1) && (r1 == mx)), off1);
-      const int i = (int)__ffsll((long long)mk) - 1;
+      unsigned long long Bq[NR];
+#pragma unroll
+      for (int k = 0; k < NR; ++k) { const int idx1 = (64 * k + l - off1) & (M - 1); Bq[k] = ballot64((idx1 < len1) && (r1[k] == mx)); }
+      int i = 0;
+      for (int base = 0; base < len1; base += 64) {
+        const unsigned long long w = ring_word<NR>(Bq, off1 + base);
+        if (w) { i = base + (int)__ffsll((long long)w) - 1; break; }
+      }
       lscore = mx; lcol = i + off1; lrow = adn - 2 - lcol;
     }
   }
-  if (lscore != undef) { extCols = lcol; extRows = lrow; return 1; }
+  if (lscore != undef) { extCols = lcol; extRows = lrow; extScore = lscore; return 1; }
   return 0;
+}
+
+// ------------------------------------------------------------------ x-drop as a wavefront recurrence
+// The unit-cost x-drop extension (match 0, mismatch -1, gap -1 — the only scoring the correction path
+// extends seeds with) computed as furthest-reaching points, one diagonal per lane (NR diagonals per
+// lane for wide x).  talc_wfa.h states the algorithm and why it returns exactly what the
+// anti-diagonal formulation returns; this is the same code, lane-parallel:
+//   F[s] of lane l = last kept anti-diagonal of diagonal k = kmin + 64 s + l, E[s] = level that reached it.
+// One level costs ~20 VALU ops plus the match-run extension (8 bases per LDS read pair), against one
+// full sweep of the band per anti-diagonal in the DP formulation.
+// Returns 1 if the seed moves, 0 if not, -1 if x needs more than 64*NR-1 diagonals or the segments do
+// not fit the LDS stage (the caller falls back to the anti-diagonal DP).
+TALC_D int lane_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x134, 0xF, 0xF, false); }
+TALC_D int wave_min_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+TALC_D unsigned long long lds_load_u64(const uint8_t TALC_AS3* p) {
+  unsigned long long v;
+  __builtin_memcpy(&v, (const void TALC_AS3*)p, 8);   // any alignment: the LDS runs in unaligned mode
+  return v;
+}
+
+template <int NR>
+TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int x,
+                          uint8_t TALC_AS3* stage, int stageCap, int& extCols, int& extRows, int& extScore,
+                          unsigned long long& cells) {
+  gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
+  const int l = lane_id();
+  qlen = uni(qlen); dlen = uni(dlen); x = uni(x);
+  extCols = extRows = extScore = 0;
+  if (qlen <= 0 || dlen <= 0) return 0;
+  const int NEG = -(1 << 29);
+  const int X = min(max(x, 0), 1 << 20);
+  const int kmin = -min(X, dlen), kmax = min(X, qlen);
+  const int nd = kmax - kmin + 1;
+  if (nd > 64 * NR - 1) return -1;   // one always-empty lane closes the ring of the lane rotations
+  // only cells with |col - row| <= x can be kept: stage that much of each segment, then a sentinel
+  const int qS = min(qlen, dlen + X), dS = min(dlen, qlen + X);
+  const int qpad = (qS + 16) & ~7;
+  if (qpad + dS + 16 > stageCap) return -1;
+  for (int i = l; i < qS; i += 64) stage[i] = querySeg[i];
+  for (int i = l; i < dS; i += 64) stage[qpad + i] = dbSeg[i];
+  if (l == 0) { stage[qS] = 0xF0; stage[qpad + dS] = 0xF1; }   // differ from each other and from every base code
+  WSYNC();
+  const int bmax = x >= 2 ? x - 1 : (x == 1 ? 1 : 0);
+  const int corner = qlen + dlen;
+  int F[NR], E[NR], amax[NR], forb[NR];
+#pragma unroll
+  for (int s = 0; s < NR; ++s) {
+    const int j = 64 * s + l, k = kmin + j, ak = k < 0 ? -k : k;
+    amax[s] = (j < nd) ? min(2 * qlen - k, 2 * dlen + k) : NEG;
+    forb[s] = (ak == bmax + 1) ? ak : -1;   // the first border cell the x-drop leaves uninitialised
+    F[s] = NEG; E[s] = 0;
+  }
+  // follow the match run of diagonal k from anti-diagonal a (lanes with act set), all slots together
+  auto extend = [&](int (&a)[NR], bool (&act)[NR]) {
+    unsigned qa[NR], da[NR];
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int k = kmin + 64 * s + l;
+      qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
+      any |= act[s];
+    }
+    while (ballot64(any) != 0ull) {
+      any = false;
+#pragma unroll
+      for (int s = 0; s < NR; ++s) {
+        if (act[s]) {
+          const unsigned long long w = lds_load_u64(stage + qa[s]) ^ lds_load_u64(stage + da[s]);
+          if (w == 0ull) { qa[s] += 8; da[s] += 8; a[s] += 16; any = true; }
+          else { a[s] += 2 * (__builtin_ctzll(w) >> 3); act[s] = false; }
+        }
+      }
+    }
+  };
+  {
+    int a0[NR]; bool act0[NR];
+    const int j0 = -kmin;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) { a0[s] = 0; act0[s] = (64 * s + l == j0) && x >= 0; }
+    extend(a0, act0);
+#pragma unroll
+    for (int s = 0; s < NR; ++s) if (64 * s + l == j0) F[s] = a0[s];
+  }
+  bool cornerHit = false;
+  int cornerE = 0;
+  {
+    unsigned long long hit = 0;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) hit |= ballot64(F[s] == corner);
+    cornerHit = hit != 0ull;
+  }
+  unsigned long long work = 0;
+  for (int e = 1; e <= x && !cornerHit; ++e) {
+    int rotR[NR], rotL[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) { rotR[s] = lane_ror1(F[s]); rotL[s] = lane_rol1(F[s]); }
+    // slots whose diagonals lie within [-e, e]
+    const int sLo = max(0, -e - kmin) >> 6, sHi = min(nd - 1, e - kmin) >> 6;
+    int b[NR]; bool act[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      b[s] = NEG; act[s] = false;
+      if (NR == 1 || (s >= sLo && s <= sHi)) {
+        const int fl = (NR > 1 && l == 0) ? rotR[(s + NR - 1) % NR] : rotR[s];   // diagonal k-1
+        const int fr = (NR > 1 && l == 63) ? rotL[(s + 1) % NR] : rotL[s];       // diagonal k+1
+        int v2 = fl + 1; v2 = (v2 <= amax[s]) ? v2 : NEG;       // gap along the query
+        int v3 = fr + 1; v3 = (v3 <= amax[s]) ? v3 : NEG;       // gap along the database
+        int v = max(max(v2, v3), min(F[s] + 2, amax[s]));       // mismatch (clamps to F itself at the matrix end)
+        v = (v == forb[s]) ? NEG : v;
+        b[s] = v;
+        act[s] = (v > F[s]) & (v >= 0);
+      }
+    }
+    bool moved[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) moved[s] = act[s];
+    extend(b, act);
+    unsigned long long hit = 0;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      if (moved[s]) { F[s] = b[s]; E[s] = e; }
+      hit |= ballot64(F[s] == corner);
+    }
+    work += (unsigned long long)min(nd, 2 * e + 1);
+    if (hit != 0ull) { cornerHit = true; cornerE = e; }
+  }
+  cells += work;
+  if (cornerHit) { extCols = qlen; extRows = dlen; extScore = -cornerE; return 1; }
+  // ---- where the anti-diagonal loop of the original stops, and the cell it reports (talc_wfa.h)
+  int mF = NEG;
+#pragma unroll
+  for (int s = 0; s < NR; ++s) mF = max(mF, F[s]);
+  const int A = wave_max_i32(mF);
+  const int cols = qlen + 1, rows = dlen + 1;
+  auto minmaxS = [&](int a, bool dropTopBorder, int& mn, int& mx) {
+    int lmn = INT_MAX, lmx = INT_MIN;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int k = kmin + 64 * s + l;
+      const int c = (a + k) >> 1;
+      const bool on = (((k - a) & 1) == 0) & (F[s] >= a) & !(dropTopBorder & (c == a));
+      if (on) { lmn = min(lmn, c); lmx = max(lmx, c); }
+    }
+    mn = wave_min_i32(lmn); mx = wave_max_i32(lmx);
+  };
+  // value of F / E on the wave-uniform diagonal k (must lie in [kmin, kmax])
+  auto at = [&](const int (&r)[NR], int k) -> int {
+    const int j = k - kmin, slot = j >> 6;
+    int v = r[0];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) if (s == slot) v = r[s];
+    return lane_get(v, j & 63);
+  };
+  auto kept = [&](int a, int c) -> bool {
+    const int k = 2 * c - a;
+    if (c < 0 || a - c < 0 || k < kmin || k > kmax) return false;
+    return at(F, k) >= a;
+  };
+  auto take = [&](int a, int c) { extCols = c; extRows = a - c; extScore = -at(E, 2 * c - a); };
+  auto firstMax = [&](int a) -> int {   // least level, then least column, among the diagonals ending on a
+    int key = INT_MAX;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int j = 64 * s + l, k = kmin + j;
+      if ((((k - a) & 1) == 0) & (F[s] == a)) key = min(key, (E[s] << 10) | j);
+    }
+    const int kk = wave_min_i32(key);
+    if (kk == INT_MAX) return 0;
+    const int k = kmin + (kk & 1023);
+    extCols = (a + k) >> 1; extRows = (a - k) >> 1; extScore = -(kk >> 10);
+    return 1;
+  };
+  bool early = false;   // the loop stops one anti-diagonal after A: every successor is outside the matrix
+  if (A + 1 >= 2) {
+    int mn, mx;
+    minmaxS(A, false, mn, mx);
+    const int lo = max(1 + mn, A + 3 - rows), hi = min(2 + mx, cols);
+    early = lo >= hi;
+  }
+  if (!early) return firstMax(A);
+  int maxColA = 1;
+  if (A >= 2) {
+    int mn1, mx1, mn2, mx2;
+    minmaxS(A - 1, true, mn1, mx1);
+    minmaxS(A - 2, false, mn2, mx2);
+    const int cm = max(mx1, mx2);
+    maxColA = (cm == INT_MIN) ? cols : min(2 + cm, cols);
+  }
+  const int c2 = maxColA - 1;
+  if (kept(A, c2)) { take(A, c2); return 1; }
+  if (A >= 2 && kept(A, c2 - 1)) { take(A, c2 - 1); return 1; }
+  return firstMax(A - 1);
 }
 
 // ------------------------------------------------------------------ k-mer window search

@@ -22,11 +22,13 @@ def pure():
     L.pure_std_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.pure_gardening.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     L.pure_sort_anchors.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    L.pure_wfa_xdrop.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
     return L
 
 
 P = pure()
 ORC.orc_sort_anchors.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+ORC.orc_xdrop_right.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
 
 
 def test_count_model_matches_oracle():
@@ -161,3 +163,53 @@ def test_anchor_ordering_matches_std_sort():
         P.pure_sort_anchors(cc, p1.ctypes.data, c1.ctypes.data, n)
         ORC.orc_sort_anchors(cc, p2.ctypes.data, c2.ctypes.data, n)
         assert p1.tolist() == p2.tolist() and c1.tolist() == c2.tolist()
+
+
+def _mutate(rnd, s, rate, alphabet):
+    out = []
+    for ch in s:
+        x = rnd.random()
+        if x < rate / 3:
+            out.append(rnd.choice(alphabet))
+        elif x < 2 * rate / 3:
+            out.append(ch)
+            out.append(rnd.choice(alphabet))
+        elif x >= rate:
+            out.append(ch)
+    return "".join(out)
+
+
+def test_wavefront_xdrop_equals_antidiagonal_xdrop():
+    """talc_wfa.h (the algorithm wave_xdrop_wfa runs on the device) against the oracle's restatement of SeqAn's
+    _extendSeedGappedXDropOneDirection for the unit-cost scoring: same decision, same extension, same score —
+    on similar and unrelated segments, tiny alphabets (long match runs), segments ending inside / beyond each
+    other (every 'longest extension' branch) and x from -1 to far beyond the segment lengths."""
+    rnd = random.Random(11)
+    seen = {0: 0, 1: 0}
+    for _ in range(12000):
+        alphabet = rnd.choice(["ACGT", "AC", "A", "ACGT"])
+        n = rnd.choice([1, 2, 3, 5, 8, 13, 30, 60, 120, 300])
+        q = "".join(rnd.choice(alphabet) for _ in range(n))
+        if rnd.random() < 0.7:
+            d = _mutate(rnd, q, rnd.choice([0, 0.02, 0.1, 0.2, 0.4]), alphabet)
+        else:
+            d = "".join(rnd.choice(alphabet) for _ in range(rnd.choice([1, 2, 4, 9, 40, 100])))
+        r = rnd.random()
+        if r < 0.25:
+            d = d[: rnd.randrange(len(d) + 1)]
+        elif r < 0.5:
+            d = d + "".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, 30)))
+        elif r < 0.6:
+            q = q[: rnd.randrange(len(q) + 1)]
+        if not q or not d:
+            continue
+        x = rnd.choice([-1, 0, 1, 2, 3, 4, 5, 7, 10, 15, 25, 40, 80, 400])
+        want = np.zeros(4, dtype=np.int32)
+        got = np.zeros(4, dtype=np.int32)
+        ORC.orc_xdrop_right(q.encode(), d.encode(), 0, -1, -1, x, want.ctypes.data)
+        P.pure_wfa_xdrop(q.encode(), len(q), d.encode(), len(d), x, got.ctypes.data)
+        assert want[0] == got[0], (q, d, x, want.tolist(), got.tolist())
+        if want[0]:
+            assert (want[1:] == got[1:]).all(), (q, d, x, want.tolist(), got.tolist())
+        seen[int(want[0])] += 1
+    assert seen[1] > 1000
