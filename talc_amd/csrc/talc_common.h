@@ -28,6 +28,7 @@ namespace talc {
 #define TALC_AS3 __attribute__((address_space(3)))
 typedef const uint8_t TALC_AS1* gcu8;
 typedef uint8_t TALC_AS1* gu8;
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // plain vector: usable through AS-qualified pointers
 #endif
 

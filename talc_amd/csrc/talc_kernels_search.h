@@ -21,7 +21,7 @@ namespace talc {
 
 #define TCAP 288          /* slots per Trail set: <= 4*max_inner_paths children, or kept + MAXB */
 #define NBUF (2 * TCAP)    /* sequence buffers shared by the two Trail sets (9 x 64) */
-#define LDS_DP_CAP 640    /* ints per DP array held in LDS; longer problems use the HBM arrays */
+#define LDS_DP_CAP 320    /* ints per DP array held in LDS; longer problems use the HBM arrays */
 #define HOT 16            /* Trail slots per set whose metadata lives in LDS (the common case has 1-8 Trails) */
 #define AIMS_LDS 64       /* target anchors kept in LDS for the aim check */
 
@@ -355,8 +355,11 @@ struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online 
   bool have; double score; double dist; double idscore; uint32_t len; uint32_t lanc, ranc;
 };
 
-enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_RECBRIDGE, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
-       PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_TOTAL, PF_N };
+enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
+       PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS, PF_NPASS, PF_NP1, PF_N };
+#define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
+                       "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
+                       "#ffpasses", "#ffp1"}
 
 struct Wv {
   // kernel constants
@@ -406,10 +409,16 @@ __shared__ unsigned long long g_prof[PF_N];
 #define PROF_DECL unsigned long long _pf_t
 #define PROF_BEGIN() (_pf_t = __builtin_amdgcn_s_memtime())
 #define PROF_END(cat) (g_prof[cat] += __builtin_amdgcn_s_memtime() - _pf_t)
+#define PROF_DECL2 unsigned long long _pf_t2
+#define PROF_BEGIN2() (_pf_t2 = __builtin_amdgcn_s_memtime())
+#define PROF_END2(cat) (g_prof[cat] += __builtin_amdgcn_s_memtime() - _pf_t2)
 #else
 #define PROF_DECL
 #define PROF_BEGIN() ((void)0)
 #define PROF_END(cat) ((void)0)
+#define PROF_DECL2
+#define PROF_BEGIN2() ((void)0)
+#define PROF_END2(cat) ((void)0)
 #endif
 
 #define COVX(i) (((const uint2 TALC_AS1*)X.cov)[(i)].x)
@@ -523,18 +532,18 @@ TALC_D void tr_sync(int t) { if (t < HOT) LSYNC(); else WSYNC(); }
 TALC_D uint32_t tr_buf(int set, int t) { return (t < HOT) ? g_hot[set * HOT + t].buf : tr_get_slow(set, t).buf; }
 TALC_D uint8_t* trail_seq(int set, int t) { return X.seqPool + (uint64_t)tr_buf(set, t) * X.C.seqCap; }
 
-// Bloom filter over the k-mers of the current search (one 64-bit word per lane = 4096 bits, two
-// probes): a superset of every live Trail's k-mers, so "definitely absent" skips the exact window
-// search of ThinkIveAlreadyGotThere (Trail.cpp:289-302); "maybe" falls through to it.
+// Bloom filter over the k-mers of the current search (one 64-bit word per lane = 4096 bits; a k-mer
+// sets two bits of one word): a superset of every live Trail's k-mers, so "definitely absent" skips
+// the exact window search of ThinkIveAlreadyGotThere (Trail.cpp:289-302); "maybe" falls through to it.
+TALC_D uint64_t bloom_hash(uint64_t kmer, uint64_t nmask) { return mix64(kmer ^ (nmask * 0x9E3779B97F4A7C15ULL)); }
+TALC_D int bloom_word(uint64_t h) { return (int)(h & 63); }
+TALC_D unsigned long long bloom_mask(uint64_t h) { return (1ull << ((h >> 6) & 63)) | (1ull << ((h >> 12) & 63)); }
 TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
-  const uint64_t h = mix64(kmer ^ (nmask * 0x9E3779B97F4A7C15ULL));
-  const int l1 = (int)(h & 63), b1 = (int)((h >> 6) & 63), l2 = (int)((h >> 12) & 63), b2 = (int)((h >> 18) & 63);
-  const unsigned long long w1 = g_bloom[l1], w2 = g_bloom[l2];
-  const bool maybe = ((w1 >> b1) & 1ull) && ((w2 >> b2) & 1ull);
-  if (lane_id() == 0) {
-    g_bloom[l1] = w1 | (1ull << b1);
-    g_bloom[l2] = (l1 == l2 ? (w1 | (1ull << b1)) : w2) | (1ull << b2);
-  }
+  const uint64_t h = bloom_hash(kmer, nmask);
+  const int w = bloom_word(h);
+  const unsigned long long m = bloom_mask(h), v = g_bloom[w];
+  const bool maybe = (v & m) == m;
+  if (lane_id() == 0) g_bloom[w] = v | m;
   LSYNC();
   return maybe;
 }
@@ -1173,72 +1182,199 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
 // The overwhelmingly common state of a search is ONE live Trail whose tip has exactly ONE
 // successor in the table.  For that state oneMoreStep / oneMoreStepInTheDark reduce to: the
 // successor is EXPECTED (counter == 1, Explorer.cpp:1251), the child inherits everything, no aim
-// is hit, no cycle, no scoring is due.  This loop performs exactly those steps with the Trail
-// held in registers, and stops BEFORE committing any step that is not of that kind (several
-// successors, dead end, aim reached, possible cycle, a scoreEdges step, limits): the generic step
-// then redoes that step from the unchanged state.  Returns the number of steps committed.
-TALC_D int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
+// is hit, no cycle, no scoring is due.  fast_forward performs exactly those steps and stops BEFORE
+// any step that is not of that kind (several successors, dead end, aim reached, possible cycle, a
+// scoreEdges step, limits): the generic step then redoes that step from the unchanged state.
+//
+// The walk is bound by instruction issue (one wave = one instruction stream), so three dependent
+// steps share one pass of instructions: lane 0 works on the tip, lanes 1-4 on the tip extended by
+// each of the four bases, lanes 5-20 on every two-base extension.  Each lane builds its k-mer,
+// fetches its bucket and takes the step's decision; the tip's decision then selects which level-1
+// lane was the real one, and that one which level-2 lane.  Every committed step is checked exactly as
+// the step-by-step walk checks it (aims, the cycle filter including the batch's own k-mers), and the
+// distance terms |c - n| / sqrt(c) are evaluated 64 steps at a time, lane-parallel, then added in
+// path order: the same double operations in the same order.
+TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
   const DevParams& P = X.P;
-  const uint32_t K = P.K;
   const int l = lane_id();
-  if (X.tracing && X.trace.steps) return 0;
-  TrailRec r = tr_get(X.ia, 0);
-  if (r.nmask) return 0;
-  const uint64_t kmask = (1ULL << (2 * K)) - 1;
-  const uint64_t m1 = (1ULL << (2 * (K - 1))) - 1;
-  const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
-  const int nAims = edge ? 0 : (X.dirRight ? X.nAncR : X.nAncL);
-  const int nl = min(nAims, AIMS_LDS);
-  gu8 seq = (gu8)(X.seqPool + (uint64_t)r.buf * X.C.seqCap);
-  const int dirRight = X.dirRight;
-  int done = 0;
-  while (stepCounter < PATH_MAXLENGTH) {
-    if (edge && ((stepCounter + 1) % P.CHECK_INTERVAL == 0)) break;          // scoreEdges is due after this step
-    if ((uint32_t)(len + 1) > X.C.seqCap) break;
-    // successors of the tip: one bucket
-    BucketRegs b;
-    const bool ok = dirRight ? probe_bucket(X.T.right, X.T.capacity, r.kmer & m1, b) : probe_bucket(X.T.left, X.T.capacity, r.kmer >> 2, b);
-    if (!ok) break;
-    int counter = 0, which = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (b.cnt[i] >= P.MIN_COUNT) { ++counter; which = i; }
-    if (counter != 1) break;
-    const uint32_t nc = (which == 0) ? b.cnt[0] : (which == 1) ? b.cnt[1] : (which == 2) ? b.cnt[2] : b.cnt[3];
-    uint64_t km2;
-    if (dirRight) km2 = ((r.kmer << 2) | (uint64_t)which) & kmask;
-    else km2 = ((uint64_t)which << (2 * (K - 1))) | (r.kmer >> 2);
-    // aim check (bridges): any hit is handled by the generic step
-    if (nAims > 0) {
-      bool hit = ballot64((l < nl) && (g_aimK[l] == km2) && (g_aimN[l] == 0ull)) != 0ull;
-      for (int ab = AIMS_LDS; ab < nAims && !hit; ab += 64) {
-        const int a = ab + l;
-        hit = ballot64((a < nAims) && (aims[a].kmer == km2) && (aims[a].nmask == 0ull)) != 0ull;
-      }
-      if (hit) break;
-    }
-    // cycle prefilter: query without inserting; a possible cycle goes to the generic step
-    const uint64_t h = mix64(km2);
-    const int l1 = (int)(h & 63), b1 = (int)((h >> 6) & 63), l2 = (int)((h >> 12) & 63), b2 = (int)((h >> 18) & 63);
-    const unsigned long long w1 = g_bloom[l1], w2 = g_bloom[l2];
-    const bool maybe = ((w1 >> b1) & 1ull) && ((w2 >> b2) & 1ull);
-    if (maybe && (len > (int)K)) break;
-    // ---- commit the step
-    if (l == 0) {
-      g_bloom[l1] = w1 | (1ull << b1);
-      g_bloom[l2] = (l1 == l2 ? (w1 | (1ull << b1)) : w2) | (1ull << b2);
-      seq[len] = (uint8_t)which;
-    }
-    LSYNC();
-    r.dist = r.dist + fabs((double)r.cnt - (double)nc) / sqrt((double)r.cnt);   // Explorer.cpp:1247, recordDistance
-    r.kmer = km2;
-    r.cnt = nc;
-    ++len; ++stepCounter; ++done;
+  // (arguments of a non-inlined function arrive in vector registers: make every one of them scalar)
+  const bool edge = uni((int)edge_) != 0;
+  if (uni((int)(X.tracing && X.trace.steps)) != 0) return 0;
+  const TrailRec r0 = tr_get(X.ia, 0);
+  if (uni64(r0.nmask) != 0ull) return 0;
+  const uint32_t K = (uint32_t)uni((int)P.K), MINC = (uint32_t)uni((int)P.MIN_COUNT), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
+  const uint32_t seqCap = (uint32_t)uni((int)X.C.seqCap), PMAX = (uint32_t)uni((int)PATH_MAXLENGTH_);
+  const int dirRight = uni((int)X.dirRight);
+  const uint64_t cap = uni64(X.T.capacity);
+  const Bucket* tab = uni_ptr(dirRight ? X.T.right : X.T.left);
+  const uint64_t kmask = (1ULL << (2 * K)) - 1, m1 = (1ULL << (2 * (K - 1))) - 1;
+  uint64_t kmer = uni64(r0.kmer);
+  uint32_t cnt = (uint32_t)uni((int)r0.cnt);
+  int len = uni(len_);
+  const int len0 = len;
+  const uint32_t sc0 = (uint32_t)uni((int)stepCounter_);
+  // number of steps this call may commit: path length limit, buffer, and (edges) the next scoreEdges step
+  int maxSteps = 0;
+  if (sc0 < PMAX && (uint32_t)len < seqCap) {
+    maxSteps = (int)min(PMAX - sc0, seqCap - (uint32_t)len);
+    if (edge) maxSteps = min(maxSteps, (int)(CHECK - 1 - (sc0 % CHECK)));
   }
+  gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
+  const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
+  const int nAims = edge ? 0 : uni(X.dirRight ? X.nAncR : X.nAncL);
+  const int nAimsLds = min(nAims, AIMS_LDS);
+  int recN = 0, recB = 0;
+  uint32_t cFlush = cnt;   // count of the tip before the first unflushed step
+  double dist = r0.dist;
+  int done = 0, flushed = 0;
+  // lane roles: level (steps ahead of the tip) and the bases assumed on the way, first base lowest
+  const int lev = (l == 0) ? 0 : (l < 5) ? 1 : 2;
+  const int asm2 = (l < 5) ? (l - 1) & 3 : (l - 5) & 15;        // level 1: b1; level 2: (b1 << 2) | b2
+  const uint32_t bitsR = (uint32_t)asm2;                         // walking RIGHT the newest base is the lowest
+  const uint32_t bitsL = (lev == 2) ? (uint32_t)(((asm2 & 3) << 2) | (asm2 >> 2)) : (uint32_t)asm2;   // LEFT: newest highest
+  const bool laneOn = l < 21;
+
+  auto flush = [&]() {
+    const int n = done - flushed;
+    if (n <= 0) return;
+    if (l < n) seq[len0 + flushed + l] = (uint8_t)recB;
+    // distance terms |c - n| / sqrt(c) (Explorer.cpp:1247): c of step j is n of step j-1
+    int cprev = lane_shr1(recN);
+    if (l == 0) cprev = (int)cFlush;
+    const double term = fabs((double)(uint32_t)cprev - (double)(uint32_t)recN) / sqrt((double)(uint32_t)cprev);
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(term);
+    const int tLo = (int)(uint32_t)tb, tHi = (int)(uint32_t)(tb >> 32);
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long v = ((unsigned long long)(uint32_t)lane_get(tHi, j) << 32) | (uint32_t)lane_get(tLo, j);
+      dist = dist + __longlong_as_double((long long)v);
+    }
+    cFlush = (uint32_t)lane_get(recN, n - 1);
+    flushed = done;
+  };
+
+  while (done < maxSteps) {
+    if (done - flushed > 60) flush();
+    const int budget = maxSteps - done;
+    // ---- this lane's tip
+    uint64_t km;
+    if (dirRight) km = ((kmer << (2 * lev)) | (uint64_t)bitsR) & kmask;
+    else km = ((kmer >> (2 * lev)) | ((uint64_t)bitsL << (2 * ((int)K - lev)))) & kmask;
+    if (lev == 0) km = kmer;
+    const uint64_t key = dirRight ? (km & m1) : (km >> 2);
+    // two consecutive slots at once: the home slot holds the key three times out of four, the next one most of the rest
+    uint64_t slot = __umul64hi(mix64(key), cap);
+    uint64_t slotB = slot + 1; if (slotB == cap) slotB = 0;
+    const v4u32 TALC_AS1* qA = (const v4u32 TALC_AS1*)(tab + slot);
+    const v4u32 TALC_AS1* qB = (const v4u32 TALC_AS1*)(tab + slotB);
+    v4u32 a = qA[0];
+    v2u32 b = *(const v2u32 TALC_AS1*)(qA + 1);
+    const v4u32 aB = qB[0];
+    const v2u32 bB = *(const v2u32 TALC_AS1*)(qB + 1);
+    uint64_t lk = ((uint64_t)a.y << 32) | a.x;
+    bool hit = (lk == key), empty = (lk == kEmptyKey);
+    if (!hit && !empty) {
+      a = aB; b = bB; slot = slotB;
+      lk = ((uint64_t)a.y << 32) | a.x;
+      hit = (lk == key); empty = (lk == kEmptyKey);
+    }
+    // aim check (bridges) and cycle prefilter need only the k-mer after this lane's step, i.e. its decision; the
+    // decision is redone if a lane on the chain has to probe further
+    int p = 0, l1 = 0, l2 = 0, i0 = 0, i1 = 0, i2 = 0;
+    int wl = 0; uint32_t ncl = 0; uint64_t km2 = 0, hb = 0; int bwi = 0; unsigned long long bm = 0;
+    while (true) {
+      // ---- this lane's decision
+      const bool g0 = a.z >= MINC, g1 = a.w >= MINC, g2 = b.x >= MINC, g3 = b.y >= MINC;
+      const int m = (g0 ? 1 : 0) | (g1 ? 2 : 0) | (g2 ? 4 : 0) | (g3 ? 8 : 0);
+      wl = __builtin_ctz((unsigned)m | 16u) & 3;
+      ncl = (g0 ? a.z : 0u) + (g1 ? a.w : 0u) + (g2 ? b.x : 0u) + (g3 ? b.y : 0u);   // = the one count, if single
+      const bool inPlay = laneOn && (lev < budget);
+      bool ok = inPlay && hit && (__builtin_popcount((unsigned)m) == 1);
+      const bool unk = inPlay && !hit && !empty;
+      if (dirRight) km2 = ((km << 2) | (uint64_t)wl) & kmask;
+      else km2 = ((uint64_t)wl << (2 * (K - 1))) | (km >> 2);
+      // aim check (bridges): a step onto an aim belongs to the generic step
+      if (nAims > 0) {
+        bool aimHit = false;
+        for (int ai = 0; ai < nAimsLds; ++ai) aimHit |= (g_aimK[ai] == km2) & (g_aimN[ai] == 0ull);
+        for (int ai = AIMS_LDS; ai < nAims; ++ai) aimHit |= (aims[ai].kmer == km2) & (aims[ai].nmask == 0ull);
+        ok = ok && !aimHit;
+      }
+      // cycle prefilter against the filter as it stands before this pass
+      hb = bloom_hash(km2, 0);
+      bwi = bloom_word(hb);
+      bm = bloom_mask(hb);
+      const unsigned long long bv = g_bloom[bwi];
+      ok = ok && !(((bv & bm) == bm) && (len + lev > (int)K));
+      // ---- resolve the chain: tip -> its level-1 lane -> its level-2 lane
+      const int info = wl | (ok ? 4 : 0) | (unk ? 8 : 0);
+      bool again = false;
+      p = 0;
+      i0 = lane_get(info, 0);
+      if (i0 & 8) again = true;
+      else if (i0 & 4) {
+        p = 1;
+        l1 = 1 + (i0 & 3);
+        i1 = lane_get(info, l1);
+        if (i1 & 8) again = true;
+        else if (i1 & 4) {
+          p = 2;
+          l2 = 5 + ((i0 & 3) << 2) + (i1 & 3);
+          i2 = lane_get(info, l2);
+          if (i2 & 8) again = true;
+          else if (i2 & 4) p = 3;
+        }
+      }
+      if (!again) break;
+      if (unk) {   // one more slot for every lane still looking for its key
+        if (++slot == cap) slot = 0;
+        const v4u32 TALC_AS1* q2 = (const v4u32 TALC_AS1*)(tab + slot);
+        a = q2[0]; b = *(const v2u32 TALC_AS1*)(q2 + 1);
+        lk = ((uint64_t)a.y << 32) | a.x;
+        hit = (lk == key); empty = (lk == kEmptyKey);
+      }
+    }
+    if (p == 0) break;
+    // the batch's own k-mers: a repeat inside the batch ends it before the repeat (the next pass sees the filter updated)
+    const int hLo = (int)(uint32_t)hb, hHi = (int)(uint32_t)(hb >> 32);
+    const uint64_t h0 = ((uint64_t)(uint32_t)lane_get(hHi, 0) << 32) | (uint32_t)lane_get(hLo, 0);
+    if (p >= 2) {
+      const uint64_t h1 = ((uint64_t)(uint32_t)lane_get(hHi, l1) << 32) | (uint32_t)lane_get(hLo, l1);
+      if (h1 == h0) p = 1;
+      else if (p == 3) {
+        const uint64_t h2 = ((uint64_t)(uint32_t)lane_get(hHi, l2) << 32) | (uint32_t)lane_get(hLo, l2);
+        if (h2 == h0 || h2 == h1) p = 2;
+      }
+    }
+    // ---- commit p steps: lanes 0, l1, l2
+    const bool com = (l == 0) || (l == l1 && p >= 2) || (l == l2 && p >= 3);
+    if (com) atomicOr(&g_bloom[bwi], bm);
+    const int base = done - flushed;
+    const int last = (p == 1) ? 0 : (p == 2) ? l1 : l2;
+    recN = lane_set(recN, lane_get((int)ncl, 0), base); recB = lane_set(recB, i0 & 3, base);
+    if (p >= 2) { recN = lane_set(recN, lane_get((int)ncl, l1), base + 1); recB = lane_set(recB, i1 & 3, base + 1); }
+    if (p >= 3) { recN = lane_set(recN, lane_get((int)ncl, l2), base + 2); recB = lane_set(recB, i2 & 3, base + 2); }
+    kmer = ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(km2 >> 32), last) << 32) | (uint32_t)lane_get((int)(uint32_t)km2, last);
+    cnt = (uint32_t)lane_get((int)ncl, last);
+    len += p; done += p;
+    LSYNC();
+#ifdef TALC_PROF_FFSTAT
+    if (l == 0) { g_prof[PF_NPASS] += 1; if (p == 1) g_prof[PF_NP1] += 1; }
+#endif
+  }
+  flush();
+  stepCounter_ = sc0 + (uint32_t)done;
+#ifdef TALC_PROF_FFSTAT
+  if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (unsigned long long)done; }
+#endif
   if (done) {
     X.steps += (unsigned long long)done;
-    if (l == 0) tr_put(X.ia, 0, r);
-    LSYNC();
+    if (l == 0) {
+      TrailRec r = r0;
+      r.kmer = kmer; r.cnt = cnt; r.dist = dist;
+      tr_put(X.ia, 0, r);
+    }
   }
+  LSYNC();
   return done;
 }
 
@@ -1275,7 +1411,7 @@ struct GapResult { bool found; uint32_t Le, Rs; uint32_t wOff, wLen; };
 
 // Explorer::searchBridge (Explorer.cpp:868-989) after initializeINNER(…, direction)
 TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
-  PROF_DECL;
+  PROF_DECL; PROF_DECL2;
   const DevParams& P = X.P;
   const uint32_t K = P.K;
   const int l = lane_id();
@@ -1310,12 +1446,14 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
     }
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
-    init_first_trail(a);
+    PROF_BEGIN2(); init_first_trail(a); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
-      if (nCur == 1) { len += fast_forward(len, stepCounter, PATH_MAXLENGTH, false); if (!(stepCounter < PATH_MAXLENGTH)) break; }
+      if (nCur == 1) { PROF_BEGIN2(); len += fast_forward(len, stepCounter, PATH_MAXLENGTH, false); PROF_END2(PF_FFWD); if (!(stepCounter < PATH_MAXLENGTH)) break; }
+      PROF_BEGIN2();
       nCur = step_bridge(nCur, len, stepCounter);
+      PROF_END2(PF_STEPB);
       ++len;
       if (X.tracing && X.trace.steps) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
     }
@@ -1385,6 +1523,7 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
 
 // Explorer::searchEdge (Explorer.cpp:992-1081) after initializeHEAD / initializeTAIL
 TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+  PROF_DECL2;
   const DevParams& P = X.P;
   const uint32_t K = P.K;
   const AnchorRec* anchors = X.dirRight ? X.ancL : X.ancR;
@@ -1409,12 +1548,14 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     }
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
-    init_first_trail(a);
+    PROF_BEGIN2(); init_first_trail(a); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
-      if (nCur == 1) { len += fast_forward(len, stepCounter, PATH_MAXLENGTH, true); if (!(stepCounter < PATH_MAXLENGTH)) break; }
+      if (nCur == 1) { PROF_BEGIN2(); len += fast_forward(len, stepCounter, PATH_MAXLENGTH, true); PROF_END2(PF_FFWD); if (!(stepCounter < PATH_MAXLENGTH)) break; }
+      PROF_BEGIN2();
       nCur = step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop);
+      PROF_END2(PF_STEPE);
       ++len;
       if (X.tracing && X.trace.steps)
         trace_rec(TR_STEP, (int)stepCounter, nCur, X.nEdges, xdrop, 0.0, nullptr, 0, false);
@@ -1490,6 +1631,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.weak = slot + C.o_weak;
   X.trace = trace;
   unsigned long long totCells = 0, totSteps = 0;
+  PROF_DECL2;
 #ifdef TALC_PROF
   if (l == 0) for (int i = 0; i < PF_N; ++i) g_prof[i] = 0;
   const unsigned long long _pf_k0 = __builtin_amdgcn_s_memtime();
@@ -1501,6 +1643,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     WSYNC();
     const uint32_t qi = s_next;
     if (qi >= n_work) break;
+    PROF_BEGIN2();
     const uint32_t r = order[qi];
     const uint64_t rb = offsets[r];
     const uint32_t L = (uint32_t)(offsets[r + 1] - rb);
@@ -1527,6 +1670,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     }
     WSYNC();
     uint32_t weakUsed = 0;
+    PROF_END2(PF_PROLOG);
     // head / tail presence as set by setInitialStructure (Read.cpp:223-237)
     bool headPresent = false, tailPresent = false;
     uint32_t headLen = 0, tailLen = 0;
@@ -1548,7 +1692,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
           build_anchors(0);
           build_anchors(1);
           trace_search();
-          success = search_bridge(wo, wl, weakUsed);
+          PROF_BEGIN2(); success = search_bridge(wo, wl, weakUsed); PROF_END2(PF_SRCHB);
           if (X.tracing) {
             if (success) trace_rec(TR_RESULT, 1, 1, (int)X.Le, (int)X.Rs, 0.0, X.weak + wo, wl, false);
             else trace_rec(TR_RESULT, 1, 0, (int)X.regE[reg], (int)X.regS[reg + 1], 0.0, X.read + X.regE[reg] + K, X.weakLen, false);
@@ -1567,7 +1711,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         X.nAncL = 0;
         build_anchors(1);
         trace_search();
-        headCorr = search_edge(headOff, headCLen, weakUsed);
+        PROF_BEGIN2(); headCorr = search_edge(headOff, headCLen, weakUsed); PROF_END2(PF_SRCHE);
         if (X.tracing) {
           if (headCorr) trace_rec(TR_RESULT, 0, 1, 0, (int)X.Rs, 0.0, X.weak + headOff, headCLen, false);
           else trace_rec(TR_RESULT, 0, 0, 0, (int)X.regS[0], 0.0, X.read, X.weakLen, false);
@@ -1584,7 +1728,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         X.nAncR = 0;
         build_anchors(0);
         trace_search();
-        tailCorr = search_edge(tailOff, tailCLen, weakUsed);
+        PROF_BEGIN2(); tailCorr = search_edge(tailOff, tailCLen, weakUsed); PROF_END2(PF_SRCHE);
         if (X.tracing) {
           if (tailCorr) trace_rec(TR_RESULT, 2, 1, (int)X.Le, 0, 0.0, X.weak + tailOff, tailCLen, false);
           else trace_rec(TR_RESULT, 2, 0, (int)X.regE[R - 1], 0, 0.0, X.read + X.regE[R - 1] + K, X.weakLen, false);
@@ -1622,6 +1766,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       continue;
     }
     uint32_t pos = 0;
+    PROF_BEGIN2();
     if (headPresent) {
       if (headCorr) { wave_copy_bytes(out + pos, X.weak + headOff, headCLen, false); pos += headCLen; }
       else { wave_copy_bytes(out + pos, X.read, headLen, false); pos += headLen; }
@@ -1640,6 +1785,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       else { wave_copy_bytes(out + pos, X.read + (L - tailLen), tailLen, false); pos += tailLen; }
     }
     if (l == 0) state[r].outLen = pos;
+    PROF_END2(PF_ASSEMBLE);
   }
   if (l == 0) {
     if (totSteps) atomicAdd((unsigned long long*)&counters[0], totSteps);

@@ -46,6 +46,13 @@ template <class T> TALC_D T* uni_ptr(T* p) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
   return (T*)(((unsigned long long)hi << 32) | lo);
 }
+// lane `lane` of `old` replaced by the wave-uniform `val` (v_writelane_b32; clang has no builtin for it)
+extern "C" __device__ int talc_llvm_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+TALC_D int lane_set(int old, int val, int lane) { return talc_llvm_writelane(val, lane, old); }
+TALC_D unsigned long long uni64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 TALC_D unsigned long long ballot64(bool p) { return __ballot(p); }
 
 // dst[0..n) = src[0..n); both 16-byte aligned, n arbitrary (tail by bytes).
