@@ -451,17 +451,50 @@ TALC_DN int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int mat
 
 // edit score (globalAlignment 0/-1/-1) and LCS length (localAlignment 1/0/0) of the same pair
 #define NW2_REG_NB 8
-TALC_DN void edit_and_lcs(const uint8_t* a, int la, const uint8_t* b, int lb, int& editScore, int& lcsLen) {
+TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, int& editScore, int& lcsLen) {
   la = uni(la); lb = uni(lb);
+  const uint8_t* a = uni_ptr(a_); const uint8_t* b = uni_ptr(b_);
   if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
-  if (la <= 64 * NW2_REG_NB) {
+  // both measures as wavefronts over the two sequences staged in LDS: the levels needed are the edit distance, and
+  // (without the substitution move) la + lb - 2 LCS
+  bool haveEdit = false, haveLcs = false;
+  constexpr int STAGE = 3 * LDS_DP_CAP * 4;
+  const int qpad = (la + 16) & ~7;
+  if (lb > 0 && qpad + lb + 16 <= STAGE) {
+    uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
+    const int l = lane_id();
+    gcu8 ga = (gcu8)a; gcu8 gb = (gcu8)b;
+    for (int i = l; i < la; i += 64) stage[i] = ga[i];
+    for (int i = l; i < lb; i += 64) stage[qpad + i] = gb[i];
+    if (l == 0) { stage[la] = 0xF0; stage[qpad + lb] = 0xF1; }
+    WSYNC();
+    unsigned long long ncells = 0;
+    int ed = -1;
+    const int lo = la - lb;   // the distance is at least the length difference
+    if (lo <= 31 && la <= 220) ed = wave_wfa_global<1, true>(stage, qpad, la, lb, ncells);
+    if (ed < 0 && lo <= 63 && la <= 440) ed = wave_wfa_global<2, true>(stage, qpad, la, lb, ncells);
+    if (ed < 0 && lo <= 127) ed = wave_wfa_global<4, true>(stage, qpad, la, lb, ncells);
+    if (ed >= 0) {
+      editScore = -ed; haveEdit = true;
+      const int hi = 2 * ed;   // each substitution is at most one insertion plus one deletion
+      int d = -1;
+      if (hi <= 31) d = wave_wfa_global<1, false>(stage, qpad, la, lb, ncells);
+      else if (hi <= 63) d = wave_wfa_global<2, false>(stage, qpad, la, lb, ncells);
+      else if (hi <= 127) d = wave_wfa_global<4, false>(stage, qpad, la, lb, ncells);
+      if (d >= 0) { lcsLen = (la + lb - d) >> 1; haveLcs = true; }
+    }
+    X.cells += ncells;
+    WSYNC();
+  }
+  if (haveEdit && haveLcs) return;
+  if (!haveEdit && !haveLcs && la <= 64 * NW2_REG_NB) {
     unsigned long long ncells = 0;
     wave_edit_lcs_reg<NW2_REG_NB>(a, la, b, lb, editScore, lcsLen, ncells);
     X.cells += ncells;
     return;
   }
-  editScore = nw_score(a, la, b, lb, 0, -1, -1, false);
-  lcsLen = nw_score(a, la, b, lb, 1, 0, 0, false);
+  if (!haveEdit) editScore = nw_score(a, la, b, lb, 0, -1, -1, false);
+  if (!haveLcs) lcsLen = nw_score(a, la, b, lb, 1, 0, 0, false);
 }
 
 // ------------------------------------------------------------------ trace helpers
@@ -1819,6 +1852,7 @@ __global__ void k_pack(const uint8_t* __restrict__ outAll, const uint64_t* __res
 // mode 1: seed_and_extension(ref=a, cand=b, xdrop, dirRight, true) -> out[0..4] = lenRefExt, lenHistExt,
 //         posOnRef, score, stop
 // mode 2: wave_find_window(a, pattern=b, wantLast=p3)              -> out[0]
+// mode 4: edit_and_lcs(a, b)                                        -> out[0] = edit score, out[1] = LCS
 __global__ void __launch_bounds__(64)
 k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, int p1, int p2, int p3, int K,
           int* dpG, uint32_t dpCap, int* out, double alpha, double err, int minc) {
@@ -1836,6 +1870,11 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
   } else if (mode == 2) {
     const int r = wave_find_window(a, la, b, lb, p3 != 0);
     if (lane_id() == 0) out[0] = r;
+  } else if (mode == 4) {
+    // mode 4: edit_and_lcs(a, b) -> out[0] = global (0,-1,-1) score, out[1] = LCS length
+    int es = 0, lcs = 0;
+    edit_and_lcs(a, la, b, lb, es, lcs);
+    if (lane_id() == 0) { out[0] = es; out[1] = lcs; out[5] = (int)X.overflow; }
   } else {
     // mode 3: tag_next_nodes on the device.  a = 4 counts + 4 colours + count as 9 little-endian u32 (36 bytes),
     // p0 = complex; out[0..3] = tags, out[4..11] = the 4 distances as raw bits

@@ -737,6 +737,104 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   return firstMax(A - 1);
 }
 
+// ------------------------------------------------------------------ global distances as wavefronts
+// Distance between two whole sequences staged in LDS (query at stage[0..qlen), database at
+// stage[qpad..qpad+dlen), each followed by its sentinel): with SUBST the edit distance (= minus the
+// global alignment score for match 0, mismatch -1, gap -1: Trail.cpp:408-434), without it the indel
+// distance qlen + dlen - 2 LCS (LCS = the localAlignment(1,0,0) optimum of Trajectory.cpp:368,525).
+// Same lane layout and level step as wave_xdrop_wfa, no drop-off: the levels run until the far corner
+// is reached.  Returns -1 if that takes more than 32*NR-1 levels (the diagonals no longer fit the lanes).
+template <int NR, bool SUBST>
+TALC_D int wave_wfa_global(const uint8_t TALC_AS3* stage, int qpad, int qlen, int dlen, unsigned long long& cells) {
+  const int l = lane_id();
+  const int NEG = -(1 << 29);
+  const int E = 32 * NR - 1;
+  const int kmin = -min(E, dlen), kmax = min(E, qlen);
+  const int nd = kmax - kmin + 1;
+  const int kc = qlen - dlen, corner = qlen + dlen;
+  if (kc < kmin || kc > kmax) return -1;
+  int F[NR], amax[NR];
+#pragma unroll
+  for (int s = 0; s < NR; ++s) {
+    const int j = 64 * s + l, k = kmin + j;
+    amax[s] = (j < nd) ? min(2 * qlen - k, 2 * dlen + k) : NEG;
+    F[s] = NEG;
+  }
+  auto extend = [&](int (&a)[NR], bool (&act)[NR]) {
+    unsigned qa[NR], da[NR];
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int k = kmin + 64 * s + l;
+      qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
+      any |= act[s];
+    }
+    while (ballot64(any) != 0ull) {
+      any = false;
+#pragma unroll
+      for (int s = 0; s < NR; ++s) {
+        if (act[s]) {
+          const unsigned long long w = lds_load_u64(stage + qa[s]) ^ lds_load_u64(stage + da[s]);
+          if (w == 0ull) { qa[s] += 8; da[s] += 8; a[s] += 16; any = true; }
+          else { a[s] += 2 * (__builtin_ctzll(w) >> 3); act[s] = false; }
+        }
+      }
+    }
+  };
+  {
+    int a0[NR]; bool act0[NR];
+    const int j0 = -kmin;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) { a0[s] = 0; act0[s] = (64 * s + l == j0); }
+    extend(a0, act0);
+#pragma unroll
+    for (int s = 0; s < NR; ++s) if (64 * s + l == j0) F[s] = a0[s];
+  }
+  {
+    unsigned long long hit = 0;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) hit |= ballot64(F[s] == corner);
+    if (hit != 0ull) return 0;
+  }
+  unsigned long long work = 0;
+  int result = -1;
+  for (int e = 1; e <= E; ++e) {
+    int rotR[NR], rotL[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) { rotR[s] = lane_ror1(F[s]); rotL[s] = lane_rol1(F[s]); }
+    const int sLo = max(0, -e - kmin) >> 6, sHi = min(nd - 1, e - kmin) >> 6;
+    int b[NR]; bool act[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      b[s] = NEG; act[s] = false;
+      if (NR == 1 || (s >= sLo && s <= sHi)) {
+        const int fl = (NR > 1 && l == 0) ? rotR[(s + NR - 1) % NR] : rotR[s];
+        const int fr = (NR > 1 && l == 63) ? rotL[(s + 1) % NR] : rotL[s];
+        int v2 = fl + 1; v2 = (v2 <= amax[s]) ? v2 : NEG;
+        int v3 = fr + 1; v3 = (v3 <= amax[s]) ? v3 : NEG;
+        int v = max(v2, v3);
+        if (SUBST) v = max(v, min(F[s] + 2, amax[s]));
+        b[s] = v;
+        act[s] = (v > F[s]) & (v >= 0);
+      }
+    }
+    bool moved[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) moved[s] = act[s];
+    extend(b, act);
+    unsigned long long hit = 0;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      if (moved[s]) F[s] = b[s];
+      hit |= ballot64(F[s] == corner);
+    }
+    work += (unsigned long long)min(nd, 2 * e + 1);
+    if (hit != 0ull) { result = e; break; }
+  }
+  cells += work;
+  return result;
+}
+
 // ------------------------------------------------------------------ k-mer window search
 // Occurrences of pat[0..K) in seq[0..len): returns the first (wantLast=false) or the last
 // (wantLast=true) start index, or -1.  Replaces Finder/Pattern<Horspool> (Trail.cpp:295-298).

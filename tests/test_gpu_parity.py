@@ -110,6 +110,42 @@ def test_device_alignment_scores_match_oracle(gpu_pair):
             assert got[5] == 0 and got[0] == exp, (n, m, mt, fb)
 
 
+def test_device_edit_distance_and_lcs_match_oracle(gpu_pair):
+    """edit_and_lcs (wavefront edit / indel distances, with the lane-skewed DP behind them) against the oracle's
+    global alignment (0,-1,-1) and LCS (localAlignment(1,0,0)): similar sequences of every size class (1, 2, 4
+    diagonals per lane), unrelated ones (the wavefronts give up, the DP takes over), N bases, empty inputs."""
+    rnd = random.Random(13)
+    L = O.lib()
+    ctx = gpu_pair.ctx
+    for it in range(90):
+        n = rnd.choice([0, 1, 5, 40, 63, 64, 65, 130, 219, 221, 400, 441, 700, 1279, 1800])
+        a = [rnd.choice("ACGTN" if rnd.random() < 0.1 else "ACGT") for _ in range(n)]
+        kind = rnd.random()
+        if kind < 0.7:
+            b = []
+            rate = rnd.choice([0.0, 0.02, 0.08, 0.15, 0.3])
+            for ch in a:
+                x = rnd.random()
+                if x < rate / 3:
+                    b.append(rnd.choice("ACGT"))
+                elif x < 2 * rate / 3:
+                    b.append(ch)
+                    b.append(rnd.choice("ACGT"))
+                elif x >= rate:
+                    b.append(ch)
+            if rnd.random() < 0.3:
+                b = b[: rnd.randrange(len(b) + 1)]
+        else:
+            b = [rnd.choice("ACGT") for _ in range(rnd.choice([0, 1, 7, 50, 64, 200, 900]))]
+        a, b = "".join(a), "".join(b)
+        if rnd.random() < 0.5:
+            a, b = b, a
+        exp_e = L.orc_global_alignment(a.encode(), b.encode(), 0, -1, -1, 0, 0, 0, 0)
+        exp_l = L.orc_global_alignment(a.encode(), b.encode(), 1, 0, 0, 0, 0, 0, 0)
+        got = ctx.test_dp(4, a, b)
+        assert got[5] == 0 and (got[0], got[1]) == (exp_e, exp_l), (len(a), len(b), got[:2].tolist(), exp_e, exp_l)
+
+
 def test_device_seed_and_extension_matches_oracle(gpu_pair):
     import ctypes as C
     rnd = random.Random(4)
