@@ -138,7 +138,19 @@ TALC_D void wave_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, u
   kmer = v;
 }
 
-// getOutDegree (Jellyfish.cpp:383-393) of a packed k-mer: uniform call, one bucket probe
+// the same for one position per lane (K byte loads each)
+TALC_D void lane_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, uint64_t& nmask) {
+  gcu8 g = (gcu8)s;
+  uint64_t v = 0, nm = 0;
+  for (int j = 0; j < K; ++j) {
+    const uint32_t c = (uint32_t)g[j];
+    v = (v << 2) | (uint64_t)((c > 3u) ? 0u : c);
+    nm |= (uint64_t)(c > 3u) << j;
+  }
+  kmer = v; nmask = nm;
+}
+
+// getOutDegree (Jellyfish.cpp:383-393) of a packed k-mer: one bucket probe (per lane, or uniform)
 TALC_D int dev_out_degree(const TableView& T, uint32_t MINC, uint64_t kmer, uint64_t nmask, int dirRight) {
   const uint32_t K = T.k;
   const uint64_t succN = dirRight ? (nmask >> 1) : (nmask & ((1ULL << (K - 1)) - 1));
@@ -153,13 +165,15 @@ TALC_D int dev_out_degree(const TableView& T, uint32_t MINC, uint64_t kmer, uint
 
 // ==================================================================== k_structure
 // Read::defineStructure2 for one read per wave.
-// S(r) = sum of the r smallest IN counts, by binary search on the value (order statistics
-// without sorting: the reference's sort only feeds a trimmed sum, Read.cpp:505-512).
-TALC_D unsigned long long trimmed_prefix_sum(const uint2* __restrict__ cov, uint32_t n, uint32_t MINC, uint32_t r) {
+// S(r) = sum of the r smallest IN counts (order statistics without sorting: the reference's sort only
+// feeds a trimmed sum, Read.cpp:505-512).  Counts below STRUCT_HBINS go through an LDS histogram (one
+// pass over the coverage, then a scan over the bins); larger ones through a bisection on the value.
+constexpr int STRUCT_HBINS = 2048, STRUCT_DEG_CAP = 1024;
+TALC_D unsigned long long trimmed_prefix_sum(const uint2* __restrict__ cov, uint32_t n, uint32_t MINC, uint32_t r, uint32_t vmax) {
   if (r == 0) return 0ull;
   const int l = lane_id();
   // smallest v with #{x >= MINC, x <= v} >= r
-  uint32_t lo = 0, hi = 0xFFFFFFFFu;
+  uint32_t lo = 0, hi = vmax;
   while (lo < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
     unsigned long long cnt = 0;
@@ -176,6 +190,26 @@ TALC_D unsigned long long trimmed_prefix_sum(const uint2* __restrict__ cov, uint
   sumLess = wave_sum_u64(sumLess);
   cntLess = wave_sum_u64(cntLess);
   return sumLess + ((unsigned long long)r - cntLess) * (unsigned long long)v;
+}
+// the same from the histogram: lane l owns bins [32 l, 32 l + 32); cBefore / sBefore = count and sum of the bins of
+// the lanes before it
+TALC_D unsigned long long hist_prefix_sum(const uint32_t* hist, unsigned long long cBefore, unsigned long long sBefore,
+                                          unsigned long long cMine, uint32_t r) {
+  if (r == 0) return 0ull;
+  const int l = lane_id();
+  const bool owner = (cBefore < (unsigned long long)r) && ((unsigned long long)r <= cBefore + cMine);
+  unsigned long long res = 0;
+  if (owner) {
+    unsigned long long c = cBefore, sm = sBefore;
+    for (int b = 0; b < STRUCT_HBINS / 64; ++b) {
+      const uint32_t v = (uint32_t)(l * (STRUCT_HBINS / 64) + b), h = hist[v];
+      if (c + h >= (unsigned long long)r) { res = sm + ((unsigned long long)r - c) * v; break; }
+      c += h; sm += (unsigned long long)h * v;
+    }
+  }
+  const unsigned long long m = ballot64(owner);
+  const int src = m ? (int)__builtin_ctzll(m) : 0;
+  return ((unsigned long long)(uint32_t)lane_get((int)(uint32_t)(res >> 32), src) << 32) | (uint32_t)lane_get((int)(uint32_t)res, src);
 }
 
 __global__ void __launch_bounds__(64)
@@ -221,22 +255,59 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   WSYNC();
 
   // ---- computeSeqErrorThreshold (Read.cpp:493-518)
+  __shared__ uint32_t s_hist[STRUCT_HBINS];
+  __shared__ uint8_t s_degS[STRUCT_DEG_CAP], s_degE[STRUCT_DEG_CAP];
   unsigned long long m = 0;
-  for (uint32_t i = l; i < n; i += 64) m += (cov[i].x >= MINC) ? 1 : 0;
+  uint32_t vmax = 0;
+  for (uint32_t i = l; i < n; i += 64) { const uint32_t x = cov[i].x; if (x >= MINC) { m += 1; vmax = max(vmax, x); } }
   m = wave_sum_u64(m);
+  vmax = wave_max_u32(vmax);
   uint32_t first = 0, last = (uint32_t)m;
   if (m > 10) { first = (uint32_t)(0.15 * (double)m); last = (uint32_t)(0.90 * (double)m); }
-  const unsigned long long sum = trimmed_prefix_sum(cov, n, MINC, last) - trimmed_prefix_sum(cov, n, MINC, first);
+  unsigned long long sum;
+  if (vmax < (uint32_t)STRUCT_HBINS) {
+    for (int b = l; b < STRUCT_HBINS; b += 64) s_hist[b] = 0;
+    WSYNC();
+    for (uint32_t i = l; i < n; i += 64) { const uint32_t x = cov[i].x; if (x >= MINC) atomicAdd(&s_hist[x], 1u); }
+    WSYNC();
+    unsigned long long cMine = 0, sMine = 0;
+    for (int b = 0; b < STRUCT_HBINS / 64; ++b) { const uint32_t v = (uint32_t)(l * (STRUCT_HBINS / 64) + b), h = s_hist[v]; cMine += h; sMine += (unsigned long long)h * v; }
+    unsigned long long cIncl = cMine, sIncl = sMine;   // inclusive scan over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long c2 = (unsigned long long)__shfl_up((long long)cIncl, off, 64), s2 = (unsigned long long)__shfl_up((long long)sIncl, off, 64);
+      if (l >= off) { cIncl += c2; sIncl += s2; }
+    }
+    sum = hist_prefix_sum(s_hist, cIncl - cMine, sIncl - sMine, cMine, last) - hist_prefix_sum(s_hist, cIncl - cMine, sIncl - sMine, cMine, first);
+  } else {
+    sum = trimmed_prefix_sum(cov, n, MINC, last, vmax) - trimmed_prefix_sum(cov, n, MINC, first, vmax);
+  }
   double robMean = (double)((unsigned long long)MINC + sum);
   robMean /= (double)(last - first);
   const double thr = robMean * P.ERR;
   st.lambda = thr;
+
+  // ---- out-degrees of every region's first k-mer (towards LEFT) and last k-mer (towards RIGHT), one region per
+  // lane: the walk below needs them one after the other, and each is a dependent probe
+  const uint32_t Rdeg = min(R, (uint32_t)STRUCT_DEG_CAP);
+  for (uint32_t base = 0; base < Rdeg; base += 64) {
+    const uint32_t reg = base + l;
+    if (reg < Rdeg) {
+      uint64_t km, nm;
+      lane_kmer_at(read + regS[reg], (int)K, km, nm);
+      s_degS[reg] = (uint8_t)dev_out_degree(T, MINC, km, nm, 0);
+      lane_kmer_at(read + regE[reg], (int)K, km, nm);
+      s_degE[reg] = (uint8_t)dev_out_degree(T, MINC, km, nm, 1);
+    }
+  }
+  WSYNC();
 
   // ---- analyzeINRegions (Read.cpp:524-600): uniform serial walk over the regions
   // new list is written in place behind a write cursor (nNew <= reg always)
   uint32_t nNew = 0;
   {
     const uint32_t solidThr = (uint32_t)thr;
+    bool startMoved = false;
     for (uint32_t reg = 0; reg < R; ++reg) {
       int span = 0;
       bool OK = true;
@@ -244,8 +315,11 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
       const uint32_t regEnd = regE[reg];
       uint64_t km, nm;
       const bool lastAndNone = ((R == reg + 1) & (nNew == 0));
-      wave_kmer_at(read + new_start_pos, (int)K, km, nm);
-      if (!lastAndNone & (dev_out_degree(T, MINC, km, nm, 0) == 0) & (new_start_pos != 0)) {
+      int degStart;
+      if (reg < Rdeg && !startMoved) degStart = (int)s_degS[reg];
+      else { wave_kmer_at(read + new_start_pos, (int)K, km, nm); degStart = dev_out_degree(T, MINC, km, nm, 0); }
+      startMoved = false;
+      if (!lastAndNone & (degStart == 0) & (new_start_pos != 0)) {
         OK = false;
         while ((new_start_pos < regEnd) & !OK) {
           ++new_start_pos;
@@ -255,8 +329,10 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
       }
       uint32_t new_end_pos = regEnd;
       if (OK & !lastAndNone) {
-        wave_kmer_at(read + new_end_pos, (int)K, km, nm);
-        if ((dev_out_degree(T, MINC, km, nm, 1) == 0) & (new_end_pos != n - 1)) {
+        int degEnd;
+        if (reg < Rdeg) degEnd = (int)s_degE[reg];
+        else { wave_kmer_at(read + new_end_pos, (int)K, km, nm); degEnd = dev_out_degree(T, MINC, km, nm, 1); }
+        if ((degEnd == 0) & (new_end_pos != n - 1)) {
           OK = false;
           while ((new_end_pos > regS[reg]) & !OK) {
             --new_end_pos;
@@ -270,6 +346,7 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
         if (span < 0) {
           if ((int)regE[reg + 1] + span >= (int)regS[reg + 1]) { if (l == 0) regS[reg + 1] = regS[reg + 1] - (uint32_t)span; }
           else { if (l == 0) regS[reg + 1] = new_start_pos; OK = false; }
+          startMoved = true;   // the next region no longer starts where its degree was taken
           WSYNC();
         }
         if (OK) {
