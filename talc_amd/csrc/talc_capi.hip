@@ -221,7 +221,9 @@ int talc_table_decolour_repeats(talc_table* t) {
   return TALC_OK;
 }
 uint64_t talc_table_size(const talc_table* t) { return t ? t->h.nkmers : 0; }
-uint64_t talc_table_device_bytes(const talc_table* t) { return t ? 2 * t->h.capacity * sizeof(Bucket) : 0; }
+uint64_t talc_table_device_bytes(const talc_table* t) {
+  return t ? 2 * t->h.capacity * sizeof(Bucket) + std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64) * 8 : 0;
+}
 
 int talc_table_upload(talc_table* t, int device) {
   if (!t) return fail(TALC_ERR_INVALID, "null table");
@@ -234,6 +236,12 @@ int talc_table_upload(talc_table* t, int device) {
   HIPCHK(hipMalloc((void**)&dc.left, bytes));
   HIPCHK(hipMemcpy(dc.right, t->h.right, bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dc.left, t->h.left, bytes, hipMemcpyHostToDevice));
+  {
+    const std::vector<uint64_t> f = t->h.buildFilter();
+    dc.filterWords = f.size();
+    HIPCHK(hipMalloc((void**)&dc.filter, f.size() * 8));
+    HIPCHK(hipMemcpy(dc.filter, f.data(), f.size() * 8, hipMemcpyHostToDevice));
+  }
   t->h.dev[device] = dc;
   t->h.frozen = true;
   return TALC_OK;
@@ -243,6 +251,7 @@ static int table_view(talc_table* t, int device, TableView& v) {
   auto it = t->h.dev.find(device);
   if (it == t->h.dev.end()) return fail(TALC_ERR_STATE, "table not uploaded to device %d", device);
   v.right = it->second.right; v.left = it->second.left; v.capacity = t->h.capacity; v.k = t->h.p.k;
+  v.filter = it->second.filter; v.filterWords = it->second.filterWords;
   return TALC_OK;
 }
 
@@ -295,7 +304,7 @@ int talc_table_lookup_host_batch(const talc_table* t, const uint64_t* kmers, uin
 void talc_table_destroy(talc_table* t) {
   if (!t) return;
   for (auto& kv : t->h.dev) {
-    if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.right); hipFree(kv.second.left); }
+    if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.right); hipFree(kv.second.left); hipFree(kv.second.filter); }
   }
   delete t;
 }

@@ -55,6 +55,11 @@ struct TableView {
   const Bucket* left;
   uint64_t capacity;     // buckets per table (any size; home = mulhi(mix64(key), capacity))
   uint32_t k;
+  // presence filter over the stored K-mers (blocked Bloom: three bits of one 64-bit word per k-mer, ~10 bits per
+  // k-mer): small enough to stay in the last-level cache, it answers most lookups of k-mers that are NOT in the
+  // table (93 % of a noisy read's k-mers) without touching the table.  nullptr / 0 = no filter.
+  const uint64_t* filter;
+  uint64_t filterWords;
 };
 
 TALC_HD uint64_t mix64(uint64_t x) {
@@ -65,6 +70,9 @@ TALC_HD uint64_t mix64(uint64_t x) {
   x ^= x >> 33;
   return x;
 }
+
+TALC_HD uint64_t filter_hash(uint64_t kmer) { return mix64(kmer ^ 0x9E3779B97F4A7C15ULL); }
+TALC_HD uint64_t filter_mask(uint64_t h) { return (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63)) | (1ULL << ((h >> 12) & 63)); }
 
 // ------------------------------------------------------------------ Dna5 codes
 // reads live in HBM as one byte per base: A=0 C=1 G=2 T=3 N=4 (SeqAn Dna5 ordinals)

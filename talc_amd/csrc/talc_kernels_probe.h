@@ -165,7 +165,12 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
     x = __builtin_bswap64(x);
     const uint64_t kmer = x >> (64 - kbits);
     uint32_t c = 0, j = 0;
-    if (nb == 0) dev_get_count(T, kmer, c, j);
+    bool maybe = (nb == 0);
+    if (maybe && T.filter) {   // presence filter first: one 8-byte word from a cache-resident array
+      const uint64_t h = filter_hash(kmer), m = filter_mask(h);
+      maybe = (T.filter[__umul64hi(h, T.filterWords)] & m) == m;
+    }
+    if (maybe) dev_get_count(T, kmer, c, j);
     out[p] = make_uint2(c, j);
     local_in += (c > min_count) ? 1 : 0;
   }

@@ -674,75 +674,89 @@ TALC_DN void build_anchors(int side) {
   const uint32_t nbKmers = re - rs + 1;
   const uint32_t pivot = side == 0 ? re : rs;
   const uint32_t limit = side == 0 ? rs : re;
-  bool goFurther = true;
-  double current_count = (double)COVX(pivot);
-  double next_count = 0;
-  uint32_t j = pivot;
+  // walk away from the pivot while each count is "expected" after the last retained one; a count that is not, but is
+  // still IN, starts a new level and is recorded (Explorer.cpp:427-447 / 493-513).  64 positions per pass: every lane
+  // tests its position against the current level; the first lane that stops either becomes the new level (the lanes
+  // behind it are tested again) or ends the walk.
+  uint32_t current_count = COVX(pivot);
   uint32_t nPos = 0;
   if (l == 0) anchorPos[0] = pivot;
   nPos = 1;
-  if (side == 0) {
-    while (goFurther & (j >= limit + 1)) {
-      next_count = (double)COVX(j - 1);
-      if ((next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) goFurther = is_expected_by_last_node(P.ALPHA, (uint32_t)next_count, (uint32_t)current_count);
-      else goFurther = false;
-      if (!goFurther & (current_count >= MINC) & (next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) {
-        if (nPos < cap) { if (l == 0) anchorPos[nPos] = j - 1; } else X.overflow |= OVF_ANCHORS;
-        if (nPos < cap) ++nPos;
-        goFurther = true;
-        current_count = next_count;
+  {
+    const uint32_t remaining = (side == 0) ? (pivot - limit) : (limit - pivot);   // positions beyond the pivot
+    bool alive = true;
+    for (uint32_t visited = 0; alive && visited < remaining; visited += 64) {
+      const uint32_t idx = visited + (uint32_t)l;
+      const bool valid = idx < remaining;
+      const uint32_t pos = (side == 0) ? (pivot - 1 - idx) : (pivot + 1 + idx);
+      const uint32_t nc = valid ? COVX(pos) : 0u;
+      const bool inRange = valid & (nc >= MINC) & ((double)nc < P.MAX_IN_COUNT);
+      int from = 0;
+      while (from < 64) {
+        const bool go = inRange && is_expected_by_last_node(P.ALPHA, nc, current_count);
+        const unsigned long long stops = ballot64(valid && !go) & (~0ull << from);
+        if (stops == 0ull) break;
+        const int f = (int)__builtin_ctzll(stops);
+        const bool fIn = ((ballot64(inRange) >> f) & 1ull) != 0ull;
+        if ((current_count >= MINC) & fIn) {
+          const uint32_t pf = (uint32_t)lane_get((int)pos, f);
+          if (nPos < cap) { if (l == 0) anchorPos[nPos] = pf; ++nPos; } else X.overflow |= OVF_ANCHORS;
+          current_count = (uint32_t)lane_get((int)nc, f);
+          from = f + 1;
+        } else { alive = false; break; }
       }
-      --j;
-    }
-  } else {
-    while (goFurther & ((j + 1) <= limit)) {
-      next_count = (double)COVX(j + 1);
-      if ((next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) goFurther = is_expected_by_last_node(P.ALPHA, (uint32_t)next_count, (uint32_t)current_count);
-      else goFurther = false;
-      if (!goFurther & (current_count >= MINC) & (next_count >= MINC) & (next_count < P.MAX_IN_COUNT)) {
-        if (nPos < cap) { if (l == 0) anchorPos[nPos] = j + 1; } else X.overflow |= OVF_ANCHORS;
-        if (nPos < cap) ++nPos;
-        goFurther = true;
-        current_count = next_count;
-      }
-      ++j;
     }
   }
   WSYNC();
   uint32_t nAnc = 0;
   uint32_t firstAnchorPos = 0;
-  for (uint32_t a = 0; a < nPos; ++a) {
-    const uint32_t pos = anchorPos[a];
-    uint64_t km, nm;
-    wave_kmer_at(X.read + pos, (int)K, km, nm);
-    const int degree = dev_out_degree(X.T, MINC, km, nm, side == 0 ? 1 : 0);
-    if ((a == 0) || ((a != 0) & (degree > 1))) {
+  for (uint32_t base = 0; base < nPos; base += 64) {   // one recorded position per lane: k-mer and out-degree
+    const uint32_t a = base + (uint32_t)l;
+    const bool valid = a < nPos;
+    const uint32_t pos = valid ? anchorPos[a] : 0u;
+    uint64_t km = 0, nm = 0;
+    int degree = 0;
+    if (valid) { lane_kmer_at(X.read + pos, (int)K, km, nm); degree = dev_out_degree(X.T, MINC, km, nm, side == 0 ? 1 : 0); }
+    unsigned long long take = ballot64(valid && ((a == 0) || (degree > 1)));
+    while (take != 0ull) {
+      const int f = (int)__builtin_ctzll(take);
+      take &= take - 1ull;
       // Explorer.cpp:454,520: the recorded count is m_coverage[anc] (loop index), not [anchorPos[anc]]
       if (nAnc < cap) {
-        if (l == 0) anc[nAnc] = AnchorRec{km, nm, pos, COVX(a)};
-        if (nAnc == 0) firstAnchorPos = pos;
+        if (l == f) anc[nAnc] = AnchorRec{km, nm, pos, COVX(a)};
+        if (nAnc == 0) firstAnchorPos = (uint32_t)lane_get((int)pos, f);
         ++nAnc;
       } else X.overflow |= OVF_ANCHORS;
     }
   }
   const uint32_t want = min(P.MIN_START_ANCHORS, nbKmers);
   if (nAnc < want) {
-    j = pivot;
-    goFurther = true;
+    const uint32_t j = pivot;
+    bool goFurther = true;
     if (side == 0) {
-      while ((j >= limit + 1) & (nAnc < want)) {
-        // :465 `for(unsigned i(0); i<size; --i)` looks at element 0 only
-        if (nAnc > 0) goFurther &= (firstAnchorPos != (j - 1));
-        if (goFurther) {
-          uint64_t km, nm;
-          wave_kmer_at(X.read + (j - 1), (int)K, km, nm);
-          const int degree = dev_out_degree(X.T, MINC, km, nm, 1);
-          if (degree > 1) {
-            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j - 1, COVX(j - 1)}; if (nAnc == 0) firstAnchorPos = j - 1; ++nAnc; }
-            else { X.overflow |= OVF_ANCHORS; break; }
-          }
+      // :461-475: walk from the pivot towards the region start and take every k-mer with out-degree > 1 until
+      // `want` anchors exist.  (:465 `for(unsigned i(0); i<size; --i)` looks at element 0 only: once the position
+      // of the FIRST anchor is met the walk records nothing more.)  One position per lane, 64 probes in flight.
+      uint32_t stopAt = limit;   // lowest position still examined
+      if (nAnc > 0 && firstAnchorPos < pivot && firstAnchorPos >= limit) stopAt = firstAnchorPos + 1;
+      const uint32_t remaining = (pivot > stopAt) ? (pivot - stopAt) : 0u;
+      bool full = false;
+      for (uint32_t visited = 0; !full && (nAnc < want) && visited < remaining; visited += 64) {
+        const uint32_t idx = visited + (uint32_t)l;
+        const bool valid = idx < remaining;
+        const uint32_t pos = pivot - 1 - (valid ? idx : 0u);
+        int degree = 0;
+        uint64_t km = 0, nm = 0;
+        if (valid) { lane_kmer_at(X.read + pos, (int)K, km, nm); degree = dev_out_degree(X.T, MINC, km, nm, 1); }
+        unsigned long long branching = ballot64(valid && degree > 1);
+        while (branching != 0ull && nAnc < want) {
+          const int f = (int)__builtin_ctzll(branching);
+          branching &= branching - 1ull;
+          if (nAnc < cap) {
+            if (l == f) anc[nAnc] = AnchorRec{km, nm, pos, COVX(pos)};
+            ++nAnc;
+          } else { X.overflow |= OVF_ANCHORS; full = true; break; }
         }
-        --j;
       }
     } else {
       // :529-540: j is DEcremented (sic); with unsigned wrap-around the loop can only ever add the
