@@ -138,6 +138,17 @@ def main():
         cov_gbs = (last.n_kmers * COV_BYTES_PER_KMER / cov_s / 1e9) if cov_s > 0 else 0.0
         search_s = (tm["search_ms"] + tm["retry_ms"]) / 1e3
         search_gbs = (last.n_trail_steps * STEP_BYTES / search_s / 1e9) if search_s > 0 else 0.0
+        # HBM traffic per launch from the committed PMC pass of this same command (rocprofv3 cannot collect counters
+        # from inside the run): only reported when the workload is the one that pass measured
+        traffic_cov = traffic_search = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "final_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("reads_per_gpu") == a.reads:
+                traffic_cov = 1024.0 * (pmc["k_coverage"]["FETCH_SIZE_KB"] + pmc["k_coverage"]["WRITE_SIZE_KB"])
+                traffic_search = 1024.0 * (pmc["k_search"]["FETCH_SIZE_KB"] + pmc["k_search"]["WRITE_SIZE_KB"])
+        except (OSError, KeyError, ValueError):
+            pass
         result = {
             "metric": "corrected long-read bases/sec (whole node); k-mer-probe HBM GB/s",
             "value": value,
@@ -162,13 +173,13 @@ def main():
             # the kernel the metric names: the k-mer coverage probe (Read::reCoverage); HBM-bound
             "roofline": {
                 "kernel": "k_coverage", "bound": "hbm", "achieved": cov_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": cov_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": cov_gbs / HBM_PEAK_GBS, "traffic": traffic_cov,
                 "algorithmic_bytes_per_launch": last.n_kmers * COV_BYTES_PER_KMER, "launch_ms": tm["coverage_ms"],
             },
             # the kernel that dominates the step time: the path search (integer DP + dependent probes)
             "roofline_search": {
                 "kernel": "k_search", "bound": "hbm", "achieved": search_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": search_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": search_gbs / HBM_PEAK_GBS, "traffic": traffic_search,
                 "algorithmic_bytes_per_launch": last.n_trail_steps * STEP_BYTES, "launch_ms": 1e3 * search_s,
                 "trail_steps": last.n_trail_steps, "dp_cells": last.n_dp_cells,
                 "dp_gcups": (last.n_dp_cells / search_s / 1e9) if search_s > 0 else 0.0,
