@@ -26,9 +26,11 @@ namespace talc {
 // restore global_* / ds_* codegen.  Only ever applied to pointers known to be HBM (AS1) or LDS (AS3).
 #define TALC_AS1 __attribute__((address_space(1)))
 #define TALC_AS3 __attribute__((address_space(3)))
+#define TALC_AS4 __attribute__((address_space(4)))   /* constant: uniform loads become scalar loads */
 typedef const uint8_t TALC_AS1* gcu8;
 typedef uint8_t TALC_AS1* gu8;
 typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+typedef uint32_t v8u32 __attribute__((ext_vector_type(8)));
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // plain vector: usable through AS-qualified pointers
 #endif
 
@@ -53,7 +55,7 @@ static const uint64_t kEmptyKey = ~0ULL;
 struct TableView {
   const Bucket* right;   // device (or host) pointer
   const Bucket* left;
-  uint64_t capacity;     // buckets per table (any size; home = mulhi(mix64(key), capacity))
+  uint64_t capacity;     // buckets per table (any size below 2^32; home = table_home(key, capacity))
   uint32_t k;
   // presence filter over the stored K-mers (blocked Bloom: three bits of one 64-bit word per k-mer, ~10 bits per
   // k-mer): small enough to stay in the last-level cache, it answers most lookups of k-mers that are NOT in the
@@ -70,6 +72,13 @@ TALC_HD uint64_t mix64(uint64_t x) {
   x ^= x >> 33;
   return x;
 }
+
+// Table hash: fold the high half of the key down, one multiply (every base of the key reaches the top bits); the
+// home slot is the high product of the top 32 hash bits and the capacity (capacity < 2^32 buckets = 137 GB per
+// table).  A lookup's address costs a handful of scalar instructions, which is what the path walk is made of.
+TALC_HD uint64_t table_hash(uint64_t key) { const uint64_t x = key ^ (key >> 29); return x * 0x9E3779B97F4A7C15ULL; }
+TALC_HD uint64_t table_slot(uint64_t h, uint64_t cap) { return ((h >> 32) * (uint64_t)(uint32_t)cap) >> 32; }
+TALC_HD uint64_t table_home(uint64_t key, uint64_t cap) { return table_slot(table_hash(key), cap); }
 
 TALC_HD uint64_t filter_hash(uint64_t kmer) { return mix64(kmer ^ 0x9E3779B97F4A7C15ULL); }
 TALC_HD uint64_t filter_mask(uint64_t h) { return (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63)) | (1ULL << ((h >> 12) & 63)); }

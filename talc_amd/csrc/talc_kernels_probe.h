@@ -6,7 +6,7 @@
 
 namespace talc {
 
-TALC_D uint64_t dev_home(uint64_t key, uint64_t cap) { return __umul64hi(mix64(key), cap); }
+TALC_D uint64_t dev_home(uint64_t key, uint64_t cap) { return table_home(key, cap); }
 
 // One bucket = two 16-byte loads from the same 32-byte sector.
 struct BucketRegs {

@@ -645,9 +645,15 @@ TALC_D uint8_t* trail_seq(int set, int t) { return X.seqPool + (uint64_t)tr_buf(
 // Bloom filter over the k-mers of the current search (one 64-bit word per lane = 4096 bits; a k-mer
 // sets two bits of one word): a superset of every live Trail's k-mers, so "definitely absent" skips
 // the exact window search of ThinkIveAlreadyGotThere (Trail.cpp:289-302); "maybe" falls through to it.
-TALC_D uint64_t bloom_hash(uint64_t kmer, uint64_t nmask) { return mix64(kmer ^ (nmask * 0x9E3779B97F4A7C15ULL)); }
-TALC_D int bloom_word(uint64_t h) { return (int)(h & 63); }
-TALC_D unsigned long long bloom_mask(uint64_t h) { return (1ull << ((h >> 6) & 63)) | (1ull << ((h >> 12) & 63)); }
+// The hash is the table hash of the k-mer's successor key (its K-1 bases on the growing side), which the
+// fast-forward loop computes anyway for the next probe.
+TALC_D uint64_t bloom_hash(uint64_t kmer, uint64_t nmask) {
+  const uint32_t K = X.P.K;
+  const uint64_t key = X.dirRight ? (kmer & ((1ULL << (2 * (K - 1))) - 1)) : (kmer >> 2);
+  return table_hash(key) ^ (nmask * 0x9E3779B97F4A7C15ULL);
+}
+TALC_D int bloom_word(uint64_t h) { return (int)(h >> 58); }
+TALC_D unsigned long long bloom_mask(uint64_t h) { return (1ull << ((h >> 52) & 63)) | (1ull << ((h >> 46) & 63)); }
 TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
   const uint64_t h = bloom_hash(kmer, nmask);
   const int w = bloom_word(h);
@@ -1304,20 +1310,22 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
 
 // ------------------------------------------------------------------ single-Trail fast-forward
 // The overwhelmingly common state of a search is ONE live Trail whose tip has exactly ONE
-// successor in the table.  For that state oneMoreStep / oneMoreStepInTheDark reduce to: the
-// successor is EXPECTED (counter == 1, Explorer.cpp:1251), the child inherits everything, no aim
-// is hit, no cycle, no scoring is due.  fast_forward performs exactly those steps and stops BEFORE
-// any step that is not of that kind (several successors, dead end, aim reached, possible cycle, a
-// scoreEdges step, limits): the generic step then redoes that step from the unchanged state.
+// successor in the table (96 % of all Trail steps).  For that state oneMoreStep /
+// oneMoreStepInTheDark reduce to: the successor is EXPECTED (counter == 1, Explorer.cpp:1251), the
+// child inherits everything, no aim is hit, no cycle, no scoring is due.  fast_forward performs
+// exactly those steps and stops BEFORE any step that is not of that kind (several successors, dead
+// end, aim reached, possible cycle, a scoreEdges step, limits): the generic step then redoes that
+// step from the unchanged state.
 //
-// The walk is bound by instruction issue (one wave = one instruction stream), so three dependent
-// steps share one pass of instructions: lane 0 works on the tip, lanes 1-4 on the tip extended by
-// each of the four bases, lanes 5-20 on every two-base extension.  Each lane builds its k-mer,
-// fetches its bucket and takes the step's decision; the tip's decision then selects which level-1
-// lane was the real one, and that one which level-2 lane.  Every committed step is checked exactly as
-// the step-by-step walk checks it (aims, the cycle filter including the batch's own k-mers), and the
-// distance terms |c - n| / sqrt(c) are evaluated 64 steps at a time, lane-parallel, then added in
-// path order: the same double operations in the same order.
+// A wave is one instruction stream and the SIMD's issue rate is what the walk is bound by, so the
+// loop is written for instruction count: everything is wave-uniform and lives on the scalar unit —
+// the bucket arrives by a scalar load (the table is read through the constant address space), its
+// address is one multiply-hash of the key, the same hash indexes the cycle filter, the filter's
+// words sit in one register pair (word i in lane i, read and written by v_readlane / v_writelane) —
+// and the per-step work that does not decide anything is batched: the committed bases and counts go
+// to lane (step mod 64) of two registers, bases are stored and the distance terms
+// |c - n| / sqrt(c) evaluated 64 steps at a time, lane-parallel, then added in path order (the same
+// double operations in the same order as the step-by-step form).
 TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
   const DevParams& P = X.P;
   const int l = lane_id();
@@ -1330,7 +1338,7 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
   const uint32_t seqCap = (uint32_t)uni((int)X.C.seqCap), PMAX = (uint32_t)uni((int)PATH_MAXLENGTH_);
   const int dirRight = uni((int)X.dirRight);
   const uint64_t cap = uni64(X.T.capacity);
-  const Bucket* tab = uni_ptr(dirRight ? X.T.right : X.T.left);
+  const Bucket TALC_AS4* tab = (const Bucket TALC_AS4*)uni_ptr(dirRight ? X.T.right : X.T.left);
   const uint64_t kmask = (1ULL << (2 * K)) - 1, m1 = (1ULL << (2 * (K - 1))) - 1;
   uint64_t kmer = uni64(r0.kmer);
   uint32_t cnt = (uint32_t)uni((int)r0.cnt);
@@ -1346,17 +1354,16 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
   gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
   const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
   const int nAims = edge ? 0 : uni(X.dirRight ? X.nAncR : X.nAncL);
-  const int nAimsLds = min(nAims, AIMS_LDS);
+  uint64_t myAim = ~0ull;   // no k-mer has the top bits set
+  if (l < min(nAims, AIMS_LDS) && g_aimN[l] == 0ull) myAim = g_aimK[l];
+  const unsigned long long bw0 = g_bloom[l];
+  int bwLo = (int)(uint32_t)bw0, bwHi = (int)(uint32_t)(bw0 >> 32);
   int recN = 0, recB = 0;
   uint32_t cFlush = cnt;   // count of the tip before the first unflushed step
   double dist = r0.dist;
   int done = 0, flushed = 0;
-  // lane roles: level (steps ahead of the tip) and the bases assumed on the way, first base lowest
-  const int lev = (l == 0) ? 0 : (l < 5) ? 1 : 2;
-  const int asm2 = (l < 5) ? (l - 1) & 3 : (l - 5) & 15;        // level 1: b1; level 2: (b1 << 2) | b2
-  const uint32_t bitsR = (uint32_t)asm2;                         // walking RIGHT the newest base is the lowest
-  const uint32_t bitsL = (lev == 2) ? (uint32_t)(((asm2 & 3) << 2) | (asm2 >> 2)) : (uint32_t)asm2;   // LEFT: newest highest
-  const bool laneOn = l < 21;
+  uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
+  uint64_t h = table_hash(key);
 
   auto flush = [&]() {
     const int n = done - flushed;
@@ -1377,115 +1384,57 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
   };
 
   while (done < maxSteps) {
-    if (done - flushed > 60) flush();
-    const int budget = maxSteps - done;
-    // ---- this lane's tip
-    uint64_t km;
-    if (dirRight) km = ((kmer << (2 * lev)) | (uint64_t)bitsR) & kmask;
-    else km = ((kmer >> (2 * lev)) | ((uint64_t)bitsL << (2 * ((int)K - lev)))) & kmask;
-    if (lev == 0) km = kmer;
-    const uint64_t key = dirRight ? (km & m1) : (km >> 2);
-    // two consecutive slots at once: the home slot holds the key three times out of four, the next one most of the rest
-    uint64_t slot = __umul64hi(mix64(key), cap);
-    uint64_t slotB = slot + 1; if (slotB == cap) slotB = 0;
-    const v4u32 TALC_AS1* qA = (const v4u32 TALC_AS1*)(tab + slot);
-    const v4u32 TALC_AS1* qB = (const v4u32 TALC_AS1*)(tab + slotB);
-    v4u32 a = qA[0];
-    v2u32 b = *(const v2u32 TALC_AS1*)(qA + 1);
-    const v4u32 aB = qB[0];
-    const v2u32 bB = *(const v2u32 TALC_AS1*)(qB + 1);
-    uint64_t lk = ((uint64_t)a.y << 32) | a.x;
-    bool hit = (lk == key), empty = (lk == kEmptyKey);
-    if (!hit && !empty) {
-      a = aB; b = bB; slot = slotB;
-      lk = ((uint64_t)a.y << 32) | a.x;
-      hit = (lk == key); empty = (lk == kEmptyKey);
-    }
-    // aim check (bridges) and cycle prefilter need only the k-mer after this lane's step, i.e. its decision; the
-    // decision is redone if a lane on the chain has to probe further
-    int p = 0, l1 = 0, l2 = 0, i0 = 0, i1 = 0, i2 = 0;
-    int wl = 0; uint32_t ncl = 0; uint64_t km2 = 0, hb = 0; int bwi = 0; unsigned long long bm = 0;
+    // ---- the tip's bucket (linear probing from its home slot)
+    uint64_t slot = table_slot(h, cap);
+    v8u32 b;
+    bool found = false;
     while (true) {
-      // ---- this lane's decision
-      const bool g0 = a.z >= MINC, g1 = a.w >= MINC, g2 = b.x >= MINC, g3 = b.y >= MINC;
-      const int m = (g0 ? 1 : 0) | (g1 ? 2 : 0) | (g2 ? 4 : 0) | (g3 ? 8 : 0);
-      wl = __builtin_ctz((unsigned)m | 16u) & 3;
-      ncl = (g0 ? a.z : 0u) + (g1 ? a.w : 0u) + (g2 ? b.x : 0u) + (g3 ? b.y : 0u);   // = the one count, if single
-      const bool inPlay = laneOn && (lev < budget);
-      bool ok = inPlay && hit && (__builtin_popcount((unsigned)m) == 1);
-      const bool unk = inPlay && !hit && !empty;
-      if (dirRight) km2 = ((km << 2) | (uint64_t)wl) & kmask;
-      else km2 = ((uint64_t)wl << (2 * (K - 1))) | (km >> 2);
-      // aim check (bridges): a step onto an aim belongs to the generic step
-      if (nAims > 0) {
-        bool aimHit = false;
-        for (int ai = 0; ai < nAimsLds; ++ai) aimHit |= (g_aimK[ai] == km2) & (g_aimN[ai] == 0ull);
-        for (int ai = AIMS_LDS; ai < nAims; ++ai) aimHit |= (aims[ai].kmer == km2) & (aims[ai].nmask == 0ull);
-        ok = ok && !aimHit;
-      }
-      // cycle prefilter against the filter as it stands before this pass
-      hb = bloom_hash(km2, 0);
-      bwi = bloom_word(hb);
-      bm = bloom_mask(hb);
-      const unsigned long long bv = g_bloom[bwi];
-      ok = ok && !(((bv & bm) == bm) && (len + lev > (int)K));
-      // ---- resolve the chain: tip -> its level-1 lane -> its level-2 lane
-      const int info = wl | (ok ? 4 : 0) | (unk ? 8 : 0);
-      bool again = false;
-      p = 0;
-      i0 = lane_get(info, 0);
-      if (i0 & 8) again = true;
-      else if (i0 & 4) {
-        p = 1;
-        l1 = 1 + (i0 & 3);
-        i1 = lane_get(info, l1);
-        if (i1 & 8) again = true;
-        else if (i1 & 4) {
-          p = 2;
-          l2 = 5 + ((i0 & 3) << 2) + (i1 & 3);
-          i2 = lane_get(info, l2);
-          if (i2 & 8) again = true;
-          else if (i2 & 4) p = 3;
-        }
-      }
-      if (!again) break;
-      if (unk) {   // one more slot for every lane still looking for its key
-        if (++slot == cap) slot = 0;
-        const v4u32 TALC_AS1* q2 = (const v4u32 TALC_AS1*)(tab + slot);
-        a = q2[0]; b = *(const v2u32 TALC_AS1*)(q2 + 1);
-        lk = ((uint64_t)a.y << 32) | a.x;
-        hit = (lk == key); empty = (lk == kEmptyKey);
-      }
+      b = *(const v8u32 TALC_AS4*)(tab + slot);
+      const uint64_t bk = ((uint64_t)b[1] << 32) | b[0];
+      if (bk == key) { found = true; break; }
+      if (bk == kEmptyKey) break;
+      if (++slot == cap) slot = 0;
     }
-    if (p == 0) break;
-    // the batch's own k-mers: a repeat inside the batch ends it before the repeat (the next pass sees the filter updated)
-    const int hLo = (int)(uint32_t)hb, hHi = (int)(uint32_t)(hb >> 32);
-    const uint64_t h0 = ((uint64_t)(uint32_t)lane_get(hHi, 0) << 32) | (uint32_t)lane_get(hLo, 0);
-    if (p >= 2) {
-      const uint64_t h1 = ((uint64_t)(uint32_t)lane_get(hHi, l1) << 32) | (uint32_t)lane_get(hLo, l1);
-      if (h1 == h0) p = 1;
-      else if (p == 3) {
-        const uint64_t h2 = ((uint64_t)(uint32_t)lane_get(hHi, l2) << 32) | (uint32_t)lane_get(hLo, l2);
-        if (h2 == h0 || h2 == h1) p = 2;
+    if (!found) break;
+    // ---- exactly one successor with count >= MIN_COUNT?
+    const uint32_t c0 = b[2], c1 = b[3], c2 = b[4], c3 = b[5];
+    const int m = (int)(c0 >= MINC) | ((int)(c1 >= MINC) << 1) | ((int)(c2 >= MINC) << 2) | ((int)(c3 >= MINC) << 3);
+    if (m == 0 || (m & (m - 1)) != 0) break;
+    const int which = __builtin_ctz((unsigned)m);
+    const uint32_t nc = (which == 0) ? c0 : (which == 1) ? c1 : (which == 2) ? c2 : c3;
+    uint64_t km2;
+    if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
+    else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
+    // ---- aim check (bridges): any hit is handled by the generic step
+    if (nAims > 0) {
+      bool hit = ballot64(myAim == km2) != 0ull;
+      for (int ab = AIMS_LDS; ab < nAims && !hit; ab += 64) {
+        const int ai = ab + l;
+        hit = ballot64((ai < nAims) && (aims[ai].kmer == km2) && (aims[ai].nmask == 0ull)) != 0ull;
       }
+      if (hit) break;
     }
-    // ---- commit p steps: lanes 0, l1, l2
-    const bool com = (l == 0) || (l == l1 && p >= 2) || (l == l2 && p >= 3);
-    if (com) atomicOr(&g_bloom[bwi], bm);
-    const int base = done - flushed;
-    const int last = (p == 1) ? 0 : (p == 2) ? l1 : l2;
-    recN = lane_set(recN, lane_get((int)ncl, 0), base); recB = lane_set(recB, i0 & 3, base);
-    if (p >= 2) { recN = lane_set(recN, lane_get((int)ncl, l1), base + 1); recB = lane_set(recB, i1 & 3, base + 1); }
-    if (p >= 3) { recN = lane_set(recN, lane_get((int)ncl, l2), base + 2); recB = lane_set(recB, i2 & 3, base + 2); }
-    kmer = ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(km2 >> 32), last) << 32) | (uint32_t)lane_get((int)(uint32_t)km2, last);
-    cnt = (uint32_t)lane_get((int)ncl, last);
-    len += p; done += p;
-    LSYNC();
-#ifdef TALC_PROF_FFSTAT
-    if (l == 0) { g_prof[PF_NPASS] += 1; if (p == 1) g_prof[PF_NP1] += 1; }
-#endif
+    // ---- cycle prefilter (query without inserting; a possible cycle goes to the generic step); the new tip's
+    // filter hash is the table hash of its successor key = the hash of the next probe
+    const uint64_t key2 = dirRight ? (km2 & m1) : (km2 >> 2);
+    const uint64_t h2 = table_hash(key2);
+    const int bwi = bloom_word(h2);
+    const unsigned long long bm = bloom_mask(h2);
+    const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
+    if (((bv & bm) == bm) && (len > (int)K)) break;
+    // ---- commit the step
+    bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
+    bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
+    const int rs = done & 63;
+    recN = lane_set(recN, (int)nc, rs);
+    recB = lane_set(recB, which, rs);
+    kmer = km2; key = key2; h = h2;
+    cnt = nc;
+    ++len; ++done;
+    if ((done & 63) == 0) flush();
   }
   flush();
+  g_bloom[l] = ((unsigned long long)(uint32_t)bwHi << 32) | (uint32_t)bwLo;
   stepCounter_ = sc0 + (uint32_t)done;
 #ifdef TALC_PROF_FFSTAT
   if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (unsigned long long)done; }

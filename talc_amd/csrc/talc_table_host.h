@@ -37,11 +37,12 @@ struct HostTable {
   uint64_t kmask() const { return (p.k >= 32) ? ~0ULL : ((1ULL << (2 * p.k)) - 1); }
 
   static inline uint64_t home(uint64_t key, uint64_t cap) {
-    return (uint64_t)(((unsigned __int128)mix64(key) * (unsigned __int128)cap) >> 64);
+    return table_home(key, cap);
   }
 
   bool allocate(uint64_t nKept) {
     capacity = nKept * 2 + 64;  // load factor <= 0.5
+    if (capacity >= (1ULL << 32)) return false;   // table_slot() addresses 2^32 buckets (137 GB) per table
     right = (Bucket*)malloc(capacity * sizeof(Bucket));
     left = (Bucket*)malloc(capacity * sizeof(Bucket));
     if (!right || !left) return false;
