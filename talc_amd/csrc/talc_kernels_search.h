@@ -21,9 +21,15 @@ namespace talc {
 
 #define TCAP 288          /* slots per Trail set: <= 4*max_inner_paths children, or kept + MAXB */
 #define NBUF (2 * TCAP)    /* sequence buffers shared by the two Trail sets (9 x 64) */
+#ifndef LDS_DP_CAP
 #define LDS_DP_CAP 320    /* ints per DP array held in LDS; longer problems use the HBM arrays */
-#define HOT 16            /* Trail slots per set whose metadata lives in LDS (the common case has 1-8 Trails) */
-#define AIMS_LDS 64       /* target anchors kept in LDS for the aim check */
+#endif
+#ifndef HOT
+#define HOT 8             /* Trail slots per set whose metadata lives in LDS (the common case has 1-8 Trails) */
+#endif
+#ifndef AIMS_LDS
+#define AIMS_LDS 16       /* target anchors kept in LDS for the aim check (a region side rarely has more than 3) */
+#endif
 
 enum : uint32_t {
   OVF_ANCHORS = 1, OVF_FULLPATHS = 2, OVF_FULLPOOL = 4, OVF_TRAILS = 8, OVF_SEQ = 16, OVF_OUT = 32, OVF_WEAKPOOL = 64,
@@ -1669,7 +1675,7 @@ TALC_D void trace_search() {
 }
 
 #ifndef TALC_SEARCH_WAVES_PER_SIMD
-#define TALC_SEARCH_WAVES_PER_SIMD 4
+#define TALC_SEARCH_WAVES_PER_SIMD 5   /* 20 waves per CU: <= 96 VGPRs and <= 8 KB of LDS per wave */
 #endif
 __global__ void __launch_bounds__(64, TALC_SEARCH_WAVES_PER_SIMD)
 k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
