@@ -175,6 +175,9 @@ def main():
                 "kernel": "k_coverage", "bound": "hbm", "achieved": cov_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": cov_gbs / HBM_PEAK_GBS, "traffic": traffic_cov,
                 "algorithmic_bytes_per_launch": last.n_kmers * COV_BYTES_PER_KMER, "launch_ms": tm["coverage_ms"],
+                # measured bytes (PMC pass) over this run's launch time: the figure BASELINE's ">= 40 % per rocprof" refers to
+                "measured_gbs": (traffic_cov / (tm["coverage_ms"] * 1e-3) / 1e9) if (traffic_cov and tm["coverage_ms"] > 0) else None,
+                "measured_frac": (traffic_cov / (tm["coverage_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic_cov and tm["coverage_ms"] > 0) else None,
             },
             # the kernel that dominates the step time: the path search (integer DP + dependent probes)
             "roofline_search": {
