@@ -59,6 +59,11 @@ struct Spec {
   double extra_error_frac, count1_frac;
   int32_t junction_period; // ~300
   uint64_t seed;
+  // paralog families (off by default, so every other field keeps producing the data it always did): with
+  // probability paralog_frac a new transcript is a mutated copy of an earlier one (substitutions at rate
+  // paralog_div, insertions and deletions at a quarter of it each), which puts bubbles and forks into the
+  // de Bruijn graph: several live Trails, gardening, bridge scoring
+  double paralog_frac, paralog_div;
 };
 
 struct Synth {
@@ -78,6 +83,7 @@ const char D[4] = {'A', 'C', 'G', 'T'};
 
 void buildTranscriptome(Synth& S) {
   Rng rng(S.sp.seed ^ 0x7A1C0001ULL);
+  Rng prng(S.sp.seed ^ 0x7A1C0009ULL);   // separate stream: the default (no paralogs) consumes none of it
   uint64_t total = 0;
   S.tstart.push_back(0);
   while (total < S.sp.target_kmers) {
@@ -86,7 +92,24 @@ void buildTranscriptome(Synth& S) {
     if (len > 30000) len = 30000;
     uint64_t L = (uint64_t)len;
     if (total + L > S.sp.target_kmers && S.sp.target_kmers - total >= 300) L = S.sp.target_kmers - total;
-    for (uint64_t i = 0; i < L; ++i) S.tx.push_back((uint8_t)(rng.next() >> 62));
+    const size_t nHave = S.tstart.size() - 1;
+    if (S.sp.paralog_frac > 0 && nHave > 0 && prng.uniform() < S.sp.paralog_frac) {
+      const size_t u = (size_t)prng.below(nHave);
+      const uint64_t b = S.tstart[u], e = S.tstart[u + 1];
+      const double dv = S.sp.paralog_div;
+      uint64_t made = 0;
+      for (uint64_t i = b; i < e; ++i) {
+        const double r = prng.uniform();
+        if (r < dv) { S.tx.push_back((uint8_t)((S.tx[i] + 1 + prng.below(3)) & 3)); ++made; }
+        else if (r < 1.25 * dv) { /* deletion */ }
+        else if (r < 1.5 * dv) { S.tx.push_back((uint8_t)(prng.next() >> 62)); S.tx.push_back(S.tx[i]); made += 2; }
+        else { S.tx.push_back(S.tx[i]); ++made; }
+      }
+      while (made < 300) { S.tx.push_back((uint8_t)(prng.next() >> 62)); ++made; }
+      L = made;
+    } else {
+      for (uint64_t i = 0; i < L; ++i) S.tx.push_back((uint8_t)(rng.next() >> 62));
+    }
     total += L;
     S.tstart.push_back(total);
     double lam = std::exp(std::log(30.0) + 1.0 * rng.normal());
@@ -232,13 +255,14 @@ struct synth_spec {
   double extra_error_frac, count1_frac;
   int32_t junction_period;
   uint64_t seed;
+  double paralog_frac, paralog_div;
 };
 
 void synth_spec_default(synth_spec* s) {
   s->target_kmers = 5000000; s->k = 21; s->mean_len = 2000; s->sd_len = 400; s->min_len = 500;
   s->mixed_lengths = 0; s->sub_rate = 0.04; s->ins_rate = 0.04; s->del_rate = 0.04;
   s->frac_short = 0.001; s->frac_random = 0.005; s->extra_error_frac = 0.10; s->count1_frac = 0.02;
-  s->junction_period = 300; s->seed = 0;
+  s->junction_period = 300; s->seed = 0; s->paralog_frac = 0.0; s->paralog_div = 0.03;
 }
 
 void* synth_create(const synth_spec* sp) {
@@ -248,6 +272,7 @@ void* synth_create(const synth_spec* sp) {
   S->sp.ins_rate = sp->ins_rate; S->sp.del_rate = sp->del_rate; S->sp.frac_short = sp->frac_short;
   S->sp.frac_random = sp->frac_random; S->sp.extra_error_frac = sp->extra_error_frac;
   S->sp.count1_frac = sp->count1_frac; S->sp.junction_period = sp->junction_period; S->sp.seed = sp->seed;
+  S->sp.paralog_frac = sp->paralog_frac; S->sp.paralog_div = sp->paralog_div;
   buildTranscriptome(*S);
   return S;
 }

@@ -26,6 +26,8 @@ class SynthSpec(C.Structure):
         ("count1_frac", C.c_double),
         ("junction_period", C.c_int32),
         ("seed", C.c_uint64),
+        ("paralog_frac", C.c_double),
+        ("paralog_div", C.c_double),
     ]
 
 

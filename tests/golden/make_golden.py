@@ -43,12 +43,17 @@ CASES = {
                       params=dict(min_count=3, window_size=6, max_nb_competing_paths=5, alpha=1.96,
                                   sr_error_rate=0.05, min_inner_score=0.5, min_border_score=0.6)),
     "g8_edge_inputs": dict(k=21, kmers=60_000, seed=108, reads=12, edge=True),
+    # paralog families: forks and bubbles in the graph -> several live Trails, gardening, bridge scoring, cycles
+    "g9_paralogs_k21": dict(k=21, kmers=80_000, seed=109, reads=24, synth=dict(paralog_frac=0.5, paralog_div=0.03)),
+    "g10_paralogs_junctions_maxb4": dict(k=21, kmers=80_000, seed=110, reads=20, junctions=True,
+                                         synth=dict(paralog_frac=0.6, paralog_div=0.015),
+                                         params=dict(max_nb_competing_paths=4, window_size=7)),
 }
 
 
 def build_case(name, c):
     k = c["k"]
-    S = Synth(target_kmers=c["kmers"], k=k, seed=c["seed"])
+    S = Synth(target_kmers=c["kmers"], k=k, seed=c["seed"], **c.get("synth", {}))
     keys, counts = S.dump_arrays()
     pk = dict(k=k, use_junctions=int(bool(c.get("junctions"))))
     pk.update(c.get("params", {}))
@@ -93,7 +98,7 @@ def build_case(name, c):
         cov, jc_, nin = tab.coverage(s)
         h.update(cov.tobytes()); h.update(jc_.tobytes())
     fx = {
-        "name": name, "params": pk, "synth": {"target_kmers": c["kmers"], "k": k, "seed": c["seed"]},
+        "name": name, "params": pk, "synth": dict({"target_kmers": c["kmers"], "k": k, "seed": c["seed"]}, **c.get("synth", {})),
         "dump_sha256": hashlib.sha256(keys.tobytes() + counts.tobytes()).hexdigest(),
         "junction_sha256": jsha, "table_size": len(tab),
         "reads": reads, "expected": corrected, "status": [int(x) for x in st], "coverage_sha256": h.hexdigest(),
@@ -106,5 +111,7 @@ def build_case(name, c):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]   # optional: names of the cases to (re)generate
     for n, c in CASES.items():
-        build_case(n, c)
+        if not only or n in only:
+            build_case(n, c)

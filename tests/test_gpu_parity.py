@@ -254,6 +254,20 @@ def test_correction_parameter_variants(kw):
     _check(pair, 0, 160)
 
 
+@pytest.mark.parametrize("synth_kw,kw", [
+    (dict(paralog_frac=0.5, paralog_div=0.03), dict()),
+    (dict(paralog_frac=0.7, paralog_div=0.06), dict(max_nb_competing_paths=4, window_size=7)),
+    (dict(paralog_frac=0.5, paralog_div=0.01), dict(max_nb_competing_paths=12, min_count=3)),
+], ids=["default", "maxb4", "maxb12"])
+def test_correction_on_branching_graphs(synth_kw, kw):
+    """Paralog families put forks and bubbles into the graph: most searches then carry several Trails, go through
+    scoreBridges / gardening (including its out-of-range read, Explorer.cpp:852) and the generic expansion step —
+    the code the unique-sequence transcriptome of the other cases hardly touches."""
+    pair = PU.Pair(target_kmers=250_000, k=21, seed=77, synth_kw=synth_kw, **kw)
+    pair.upload(0)
+    _check(pair, 0, 200)
+
+
 def test_correction_with_junction_colours():
     pair = PU.Pair(target_kmers=300_000, k=21, seed=31, junctions=True)
     pair.upload(0)
