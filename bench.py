@@ -66,7 +66,7 @@ def main():
     synth = Synth(target_kmers=a.kmers, k=a.k, seed=a.seed)
     keys, counts = synth.dump_arrays()
     params = T.default_params(k=a.k)
-    table = T.Table.from_arrays(keys, counts, params)
+    table = T.Table.from_arrays(keys, counts, params, device=dev)   # insertion on the GPU (untimed setup)
     table.decolour_repeats()
     n_table = len(table)
     table.upload(dev)

@@ -106,6 +106,14 @@ int talc_table_build(const char* dump_path, const char* junction_path, const tal
  * first-duplicate-wins rule are applied here).  No colouring, no de-colouring. */
 int talc_table_from_arrays(const uint64_t* kmers, const uint32_t* counts, uint64_t n,
                            const talc_params* p, talc_table** out);
+/* The same two builders with the insert loop of buildCDBG (Jellyfish.cpp:251-269) run on GPU `device`
+ * (parallel text parse on the host, CAS insertion with the first-duplicate-wins rule on the device); the
+ * result is an ordinary talc_table (host image filled from the device), identical in content: every lookup
+ * returns what it returns on a host-built table.  Fails with TALC_ERR_DEVICE when the GPU cannot be used. */
+int talc_table_build_device(const char* dump_path, const char* junction_path, const talc_params* p,
+                            int device, talc_table** out, int64_t stats[3]);
+int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts, uint64_t n,
+                                  const talc_params* p, int device, talc_table** out);
 /* Junction colouring on arrays, in order, both strands (Jellyfish.cpp:278-289). */
 int talc_table_colour(talc_table* t, const uint64_t* jkmers, const int64_t* jcounts, uint64_t n);
 /* decolourRepeatsFromDBG (utils.cpp:658-669). */

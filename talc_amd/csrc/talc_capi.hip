@@ -15,6 +15,7 @@
 
 #include "talc_common.h"
 #include "talc_hip.h"
+#include "talc_kernels_build.h"
 #include "talc_kernels_probe.h"
 #include "talc_kernels_search.h"
 #include "talc_table_host.h"
@@ -154,58 +155,92 @@ int talc_table_from_arrays(const uint64_t* kmers, const uint32_t* counts, uint64
   return TALC_OK;
 }
 
-int talc_table_build(const char* dump_path, const char* junction_path, const talc_params* p, talc_table** out,
-                     int64_t stats[3]) {
+// the table built on `device` (talc_kernels_build.h), then copied back so that the object is a complete talc_table
+// (host lookups, colouring, upload to any device)
+int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts, uint64_t n, const talc_params* p, int device,
+                                  talc_table** out) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!out || (n && (!kmers || !counts))) return fail(TALC_ERR_INVALID, "null argument");
+  if (n >= 0xFFFFFFFEull) return fail(TALC_ERR_INVALID, "the device builder takes fewer than 2^32-2 entries");
+  uint64_t kept = 0;
+#pragma omp parallel for reduction(+ : kept)
+  for (long i = 0; i < (long)n; ++i) kept += counts[i] >= p->min_count ? 1 : 0;
+  talc_table* t = new talc_table();
+  t->h.p = *p;
+  if (!t->h.allocate(kept, false)) { delete t; return fail(TALC_ERR_NOMEM, "cannot allocate host table for %llu k-mers", (unsigned long long)kept); }
+  const uint64_t cap = t->h.capacity, bytes = cap * sizeof(Bucket);
+  Bucket *dR = nullptr, *dL = nullptr;
+  uint64_t* dK = nullptr; uint32_t *dC = nullptr, *dSR = nullptr, *dSL = nullptr;
+  unsigned long long* dStats = nullptr;
+  auto cleanup = [&]() { hipFree(dR); hipFree(dL); hipFree(dK); hipFree(dC); hipFree(dSR); hipFree(dSL); hipFree(dStats); };
+#define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); delete t; return fail(TALC_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  BCHK(hipSetDevice(device));
+  BCHK(hipMalloc((void**)&dR, bytes)); BCHK(hipMalloc((void**)&dL, bytes));
+  BCHK(hipMalloc((void**)&dK, std::max<uint64_t>(n, 1) * 8)); BCHK(hipMalloc((void**)&dC, std::max<uint64_t>(n, 1) * 4));
+  BCHK(hipMalloc((void**)&dSR, std::max<uint64_t>(n, 1) * 4)); BCHK(hipMalloc((void**)&dSL, std::max<uint64_t>(n, 1) * 4));
+  BCHK(hipMalloc((void**)&dStats, 3 * 8));
+  BCHK(hipMemset(dR, 0xFF, bytes)); BCHK(hipMemset(dL, 0xFF, bytes)); BCHK(hipMemset(dStats, 0, 3 * 8));
+  if (n) { BCHK(hipMemcpy(dK, kmers, n * 8, hipMemcpyHostToDevice)); BCHK(hipMemcpy(dC, counts, n * 4, hipMemcpyHostToDevice)); }
+  BCHK(hipDeviceSynchronize());
+  if (n) {
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_build_claim, dim3(nb), dim3(256), 0, 0, dR, dL, cap, p->k, dK, dC, n, p->min_count, dSR, dSL);
+    hipLaunchKernelGGL(k_build_resolve, dim3(nb), dim3(256), 0, 0, dR, dL, p->k, dK, n, dSR, dSL);
+    hipLaunchKernelGGL(k_build_write, dim3(nb), dim3(256), 0, 0, dR, dL, p->k, dK, dC, n, dSR, dSL);
+  }
+  hipLaunchKernelGGL(k_build_finalize, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, 0, dR, dL, cap, dStats);
+  BCHK(hipGetLastError());
+  BCHK(hipDeviceSynchronize());
+  unsigned long long st[3];
+  BCHK(hipMemcpy(st, dStats, 3 * 8, hipMemcpyDeviceToHost));
+  BCHK(hipMemcpy(t->h.right, dR, bytes, hipMemcpyDeviceToHost));
+  BCHK(hipMemcpy(t->h.left, dL, bytes, hipMemcpyDeviceToHost));
+#undef BCHK
+  cleanup();
+  t->h.nkmers = st[0]; t->h.nbuckets_right = st[1]; t->h.nbuckets_left = st[2];
+  *out = t;
+  return TALC_OK;
+}
+
+static int table_build_impl(const char* dump_path, const char* junction_path, const talc_params* p, int device, talc_table** out,
+                            int64_t stats[3]) {
   int rc = check_params(p);
   if (rc) return rc;
   if (!dump_path || !out) return fail(TALC_ERR_INVALID, "null argument");
   // Jellyfish.cpp:251-269: whitespace-separated "kmer count" per line
-  FILE* f = fopen(dump_path, "r");
-  if (!f) return fail(TALC_ERR_IO, "cannot open %s", dump_path);
   std::vector<uint64_t> kmers;
   std::vector<uint32_t> counts;
-  int64_t nread = 0, nkept = 0, nbad = 0;
-  char line[4096], km[2048], cs[2048];
-  while (fgets(line, sizeof line, f)) {
-    if (sscanf(line, "%2047s %2047s", km, cs) == 2) {
-      int c = atoi(cs);  // std::stoi in the reference
-      nread++;
-      if ((unsigned int)c >= p->min_count) {  // int vs unsigned compare (Jellyfish.cpp:260)
-        nkept++;
-        uint64_t packed;
-        // k-mers that are not K letters of ACGT can never equal a read k-mer's text unless the
-        // read k-mer has N at the same places; those are not representable and are dropped.
-        if (packText(km, strlen(km), p->k, packed)) { kmers.push_back(packed); counts.push_back((uint32_t)c); }
-      }
-    } else {
-      nbad++;
-    }
-  }
-  fclose(f);
+  DumpStats ds;
+  if (!parseDumpFile(dump_path, p->k, p->min_count, true, kmers, &counts, nullptr, ds)) return fail(TALC_ERR_IO, "cannot open %s", dump_path);
   talc_table* t = nullptr;
-  rc = talc_table_from_arrays(kmers.data(), counts.data(), kmers.size(), p, &t);
+  rc = (device >= 0) ? talc_table_from_arrays_device(kmers.data(), counts.data(), kmers.size(), p, device, &t)
+                     : talc_table_from_arrays(kmers.data(), counts.data(), kmers.size(), p, &t);
   if (rc) return rc;
   std::vector<uint64_t>().swap(kmers);
   std::vector<uint32_t>().swap(counts);
   if (junction_path && junction_path[0]) {  // Jellyfish.cpp:273-290
-    FILE* jf = fopen(junction_path, "r");
-    if (!jf) { delete t; return fail(TALC_ERR_IO, "cannot open %s", junction_path); }
     std::vector<uint64_t> jk;
     std::vector<int64_t> jc;
-    while (fgets(line, sizeof line, jf)) {
-      if (sscanf(line, "%2047s %2047s", km, cs) == 2) {
-        uint64_t packed;
-        if (packText(km, strlen(km), p->k, packed)) { jk.push_back(packed); jc.push_back((int64_t)atoi(cs)); }
-      } else
-        nbad++;
-    }
-    fclose(jf);
+    DumpStats js;
+    if (!parseDumpFile(junction_path, p->k, 0, false, jk, nullptr, &jc, js)) { delete t; return fail(TALC_ERR_IO, "cannot open %s", junction_path); }
+    ds.nbad += js.nbad;
     t->h.colour(jk.data(), jc.data(), jk.size());
   }
   t->h.decolourRepeats();  // main.cpp:232
-  if (stats) { stats[0] = nread; stats[1] = nkept; stats[2] = nbad; }
+  if (stats) { stats[0] = ds.nread; stats[1] = ds.nkept; stats[2] = ds.nbad; }
   *out = t;
   return TALC_OK;
+}
+
+int talc_table_build(const char* dump_path, const char* junction_path, const talc_params* p, talc_table** out,
+                     int64_t stats[3]) {
+  return table_build_impl(dump_path, junction_path, p, -1, out, stats);
+}
+int talc_table_build_device(const char* dump_path, const char* junction_path, const talc_params* p, int device,
+                            talc_table** out, int64_t stats[3]) {
+  if (device < 0) return fail(TALC_ERR_INVALID, "device must be >= 0");
+  return table_build_impl(dump_path, junction_path, p, device, out, stats);
 }
 
 int talc_table_colour(talc_table* t, const uint64_t* jkmers, const int64_t* jcounts, uint64_t n) {

@@ -1,0 +1,100 @@
+// talc_kernels_build.h — the k-mer table built on the device (replaces the insert loop of buildCDBG,
+// Jellyfish.cpp:251-269, for arrays of packed k-mers).
+//
+// Semantics to keep: only k-mers with count >= min_count are stored, and of several lines with the same
+// k-mer the FIRST one wins (std::map::insert, Jellyfish.cpp:262).  Four passes over the n entries:
+//   claim     every kept entry finds or claims the bucket of its (K-1)-mer key in both tables (64-bit CAS, linear
+//             probing from the same home slot the lookups use) and bids for its count slot with atomicMin(index+1)
+//             — the count words, preset to 0xFFFFFFFF, hold the smallest bidding index after this pass;
+//   resolve   an entry whose index is not the one left in the slot lost to an earlier line: it forgets its slot;
+//   write     the winners store their counts;
+//   finalize  untouched count words and colour fields become 0; stored k-mers and buckets are counted.
+// Bucket placement along a probe sequence depends on the order the CASes land in, which is not the host builder's
+// order; lookups do not depend on it (no deletions, probing stops at the first empty bucket).
+#pragma once
+#include "talc_common.h"
+
+namespace talc {
+
+static constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+TALC_D uint32_t build_claim_bucket(Bucket* tab, uint64_t cap, uint64_t key) {
+  uint64_t i = table_home(key, cap);
+  while (true) {
+    unsigned long long* kp = (unsigned long long*)&tab[i].key;
+    unsigned long long cur = __atomic_load_n(kp, __ATOMIC_RELAXED);
+    if (cur == kEmptyKey) cur = atomicCAS(kp, (unsigned long long)kEmptyKey, (unsigned long long)key) == kEmptyKey ? key : __atomic_load_n(kp, __ATOMIC_RELAXED);
+    if (cur == key) return (uint32_t)i;
+    if (++i == cap) i = 0;
+  }
+}
+
+__global__ void k_build_claim(Bucket* right, Bucket* left, uint64_t cap, uint32_t K, const uint64_t* __restrict__ kmers,
+                              const uint32_t* __restrict__ counts, uint64_t n, uint32_t minc, uint32_t* __restrict__ slotR,
+                              uint32_t* __restrict__ slotL) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (counts[i] < minc) { slotR[i] = kNoSlot; slotL[i] = kNoSlot; return; }
+  const uint64_t km = kmers[i];
+  const uint64_t m1 = (1ULL << (2 * (K - 1))) - 1;
+  const uint32_t sr = build_claim_bucket(right, cap, km >> 2);
+  atomicMin(&right[sr].cnt[km & 3], (uint32_t)(i + 1));
+  const uint32_t sl = build_claim_bucket(left, cap, km & m1);
+  atomicMin(&left[sl].cnt[(km >> (2 * (K - 1))) & 3], (uint32_t)(i + 1));
+  slotR[i] = sr; slotL[i] = sl;
+}
+
+__global__ void k_build_resolve(const Bucket* __restrict__ right, const Bucket* __restrict__ left, uint32_t K,
+                                const uint64_t* __restrict__ kmers, uint64_t n, uint32_t* __restrict__ slotR,
+                                uint32_t* __restrict__ slotL) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t km = kmers[i];
+  const uint32_t sr = slotR[i], sl = slotL[i];
+  if (sr != kNoSlot && right[sr].cnt[km & 3] != (uint32_t)(i + 1)) slotR[i] = kNoSlot;
+  if (sl != kNoSlot && left[sl].cnt[(km >> (2 * (K - 1))) & 3] != (uint32_t)(i + 1)) slotL[i] = kNoSlot;
+}
+
+__global__ void k_build_write(Bucket* right, Bucket* left, uint32_t K, const uint64_t* __restrict__ kmers,
+                              const uint32_t* __restrict__ counts, uint64_t n, const uint32_t* __restrict__ slotR,
+                              const uint32_t* __restrict__ slotL) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t km = kmers[i];
+  const uint32_t sr = slotR[i], sl = slotL[i];
+  if (sr != kNoSlot) right[sr].cnt[km & 3] = counts[i];
+  if (sl != kNoSlot) left[sl].cnt[(km >> (2 * (K - 1))) & 3] = counts[i];
+}
+
+// stats: [0] stored k-mers (RIGHT table), [1] buckets RIGHT, [2] buckets LEFT
+__global__ void k_build_finalize(Bucket* right, Bucket* left, uint64_t cap, unsigned long long* stats) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long nk = 0, nr = 0, nl = 0;
+  if (j < cap) {
+    for (int which = 0; which < 2; ++which) {
+      Bucket* b = (which == 0 ? right : left) + j;
+      const bool used = b->key != kEmptyKey;
+      for (int c = 0; c < 4; ++c) {
+        uint32_t v = b->cnt[c];
+        if (!used || v == 0xFFFFFFFFu) v = 0;
+        b->cnt[c] = v; b->jc[c] = 0;
+        if (which == 0 && v != 0) ++nk;
+      }
+      if (used) { if (which == 0) ++nr; else ++nl; }
+    }
+  }
+  // block reduction (256 threads)
+  __shared__ unsigned long long s[3];
+  if (threadIdx.x == 0) { s[0] = s[1] = s[2] = 0; }
+  __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) {
+    nk += (unsigned long long)__shfl_down((long long)nk, off, 64);
+    nr += (unsigned long long)__shfl_down((long long)nr, off, 64);
+    nl += (unsigned long long)__shfl_down((long long)nl, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&s[0], nk); atomicAdd(&s[1], nr); atomicAdd(&s[2], nl); }
+  __syncthreads();
+  if (threadIdx.x == 0) { if (s[0]) atomicAdd(&stats[0], s[0]); if (s[1]) atomicAdd(&stats[1], s[1]); if (s[2]) atomicAdd(&stats[2], s[2]); }
+}
+
+}  // namespace talc

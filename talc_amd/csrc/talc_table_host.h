@@ -1,6 +1,11 @@
 // talc_table_host.h — host-side construction of the successor-grouped k-mer table
 // (replaces buildCDBG, Jellyfish.cpp:236-295, and decolourRepeatsFromDBG, utils.cpp:658-669).
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cstring>
 #include <omp.h>
 
 #include <cstdio>
@@ -40,12 +45,13 @@ struct HostTable {
     return table_home(key, cap);
   }
 
-  bool allocate(uint64_t nKept) {
+  bool allocate(uint64_t nKept, bool clear = true) {
     capacity = nKept * 2 + 64;  // load factor <= 0.5
     if (capacity >= (1ULL << 32)) return false;   // table_slot() addresses 2^32 buckets (137 GB) per table
     right = (Bucket*)malloc(capacity * sizeof(Bucket));
     left = (Bucket*)malloc(capacity * sizeof(Bucket));
     if (!right || !left) return false;
+    if (!clear) return true;   // (the device builder overwrites both images)
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)capacity; ++i) {
       right[i].key = kEmptyKey; left[i].key = kEmptyKey;
@@ -92,6 +98,7 @@ struct HostTable {
     for (int which = 0; which < 2; ++which) {
       Bucket* tab = which == 0 ? right : left;
       int T = omp_get_max_threads();
+      if (T > 16) T = 16;   // every thread scans the whole array: more threads only add redundant scanning
       if (n < 100000) T = 1;
       std::vector<std::vector<uint64_t>> deferred(T);
       std::vector<uint64_t> added(T, 0), newb(T, 0);
@@ -201,6 +208,98 @@ static inline bool packText(const char* s, size_t len, uint32_t K, uint64_t& out
     v = (v << 2) | c;
   }
   out = v;
+  return true;
+}
+
+// "kmer count" lines (Jellyfish.cpp:251-269: whitespace-separated tokens, count by std::stoi, kept if
+// (unsigned)count >= min_count, Jellyfish.cpp:260) from a memory-mapped file, parsed in parallel over chunks cut at
+// line ends; the kept entries come out in file order (first duplicate wins later on).  Lines without two tokens are
+// counted as bad; kept k-mers that are not K letters of ACGT are not representable and dropped.
+// wantCounts false: the second token is returned as a signed count for every line (junction dumps).
+struct DumpStats { int64_t nread = 0, nkept = 0, nbad = 0; };
+static inline bool parseDumpFile(const char* path, uint32_t K, uint32_t minc, bool filter, std::vector<uint64_t>& kmers,
+                                 std::vector<uint32_t>* counts, std::vector<int64_t>* scounts, DumpStats& st) {
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return false;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); return false; }
+  const size_t size = (size_t)sb.st_size;
+  if (size == 0) { close(fd); return true; }
+  const char* base = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (base == MAP_FAILED) return false;
+  int T = omp_get_max_threads();
+  if (T > 64) T = 64;
+  if (size < (1u << 20)) T = 1;
+  std::vector<size_t> cut(T + 1, size);
+  cut[0] = 0;
+  for (int t = 1; t < T; ++t) {
+    size_t p = size / T * t;
+    while (p < size && base[p - 1] != '\n') ++p;
+    cut[t] = p;
+  }
+  std::vector<std::vector<uint64_t>> lk(T);
+  std::vector<std::vector<uint32_t>> lc(T);
+  std::vector<std::vector<int64_t>> ls(T);
+  std::vector<DumpStats> lst(T);
+#pragma omp parallel num_threads(T)
+  {
+    const int t = omp_get_thread_num();
+    const char* p = base + cut[t];
+    const char* end = base + cut[t + 1];
+    auto isws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
+    DumpStats s;
+    while (p < end) {
+      const char* eol = (const char*)memchr(p, '\n', (size_t)(end - p));
+      if (!eol) eol = end;
+      const char* q = p;
+      while (q < eol && isws(*q)) ++q;
+      const char* k0 = q;
+      while (q < eol && !isws(*q)) ++q;
+      const char* k1 = q;
+      while (q < eol && isws(*q)) ++q;
+      const char* c0 = q;
+      while (q < eol && !isws(*q)) ++q;
+      const char* c1 = q;
+      if (k1 > k0 && c1 > c0) {
+        // atoi: optional sign, then digits; anything else stops the number (0 if none)
+        long long v = 0; bool neg = false; const char* d = c0;
+        if (d < c1 && (*d == '+' || *d == '-')) { neg = (*d == '-'); ++d; }
+        while (d < c1 && *d >= '0' && *d <= '9') { v = v * 10 + (*d - '0'); if (v > 0x7fffffffLL) v = 0x7fffffffLL; ++d; }
+        const int c = (int)(neg ? -v : v);
+        s.nread++;
+        if (!filter || (unsigned int)c >= minc) {
+          if (filter) s.nkept++;
+          uint64_t packed;
+          if (packText(k0, (size_t)(k1 - k0), K, packed)) {
+            lk[t].push_back(packed);
+            if (counts) lc[t].push_back((uint32_t)c);
+            if (scounts) ls[t].push_back((int64_t)c);
+          }
+        }
+      } else {
+        s.nbad++;   // (fgets + sscanf counted every line that did not yield two tokens, blank ones included)
+      }
+      p = eol + 1;
+    }
+    lst[t] = s;
+  }
+  munmap((void*)base, size);
+  size_t total = 0;
+  for (int t = 0; t < T; ++t) total += lk[t].size();
+  kmers.resize(total);
+  if (counts) counts->resize(total);
+  if (scounts) scounts->resize(total);
+  size_t off = 0;
+  for (int t = 0; t < T; ++t) {
+    if (!lk[t].empty()) {
+      memcpy(kmers.data() + off, lk[t].data(), lk[t].size() * 8);
+      if (counts) memcpy(counts->data() + off, lc[t].data(), lc[t].size() * 4);
+      if (scounts) memcpy(scounts->data() + off, ls[t].data(), ls[t].size() * 8);
+    }
+    off += lk[t].size();
+    st.nread += lst[t].nread; st.nkept += lst[t].nkept; st.nbad += lst[t].nbad;
+  }
   return true;
 }
 

@@ -21,7 +21,8 @@ LOG_MESSAGES = {
 # every symbol include/talc_hip.h declares
 ABI_SYMBOLS = [
     "talc_abi_version", "talc_last_error", "talc_params_default", "talc_device_count",
-    "talc_table_build", "talc_table_from_arrays", "talc_table_colour", "talc_table_decolour_repeats",
+    "talc_table_build", "talc_table_from_arrays", "talc_table_build_device", "talc_table_from_arrays_device",
+    "talc_table_colour", "talc_table_decolour_repeats",
     "talc_table_size", "talc_table_device_bytes", "talc_table_upload", "talc_table_lookup_batch",
     "talc_table_next_counts_batch", "talc_table_lookup_host_batch", "talc_table_destroy",
     "talc_ctx_create", "talc_ctx_destroy", "talc_batch_create", "talc_batch_destroy",
@@ -100,6 +101,8 @@ def lib():
         L.talc_params_default.argtypes = [C.POINTER(Params)]
         L.talc_table_build.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Params), C.POINTER(vp), vp]
         L.talc_table_from_arrays.argtypes = [vp, vp, u64, C.POINTER(Params), C.POINTER(vp)]
+        L.talc_table_build_device.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Params), i32, C.POINTER(vp), vp]
+        L.talc_table_from_arrays_device.argtypes = [vp, vp, u64, C.POINTER(Params), i32, C.POINTER(vp)]
         L.talc_table_colour.argtypes = [vp, vp, vp, u64]
         L.talc_table_decolour_repeats.argtypes = [vp]
         L.talc_table_size.restype = u64
@@ -162,18 +165,27 @@ class Table:
         self.params = params
 
     @classmethod
-    def from_arrays(cls, kmers, counts, params):
+    def from_arrays(cls, kmers, counts, params, device=None):
+        """device=None: host builder; device=d: insertion on GPU d (same content)."""
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
         counts = np.ascontiguousarray(counts, dtype=np.uint32)
         h = C.c_void_p()
-        _chk(lib().talc_table_from_arrays(kmers.ctypes.data, counts.ctypes.data, len(kmers), C.byref(params), C.byref(h)))
+        if device is None:
+            _chk(lib().talc_table_from_arrays(kmers.ctypes.data, counts.ctypes.data, len(kmers), C.byref(params), C.byref(h)))
+        else:
+            _chk(lib().talc_table_from_arrays_device(kmers.ctypes.data, counts.ctypes.data, len(kmers), C.byref(params),
+                                                     int(device), C.byref(h)))
         return cls(h, params)
 
     @classmethod
-    def from_files(cls, dump, junctions, params):
+    def from_files(cls, dump, junctions, params, device=None):
         h = C.c_void_p()
         st = np.zeros(3, dtype=np.int64)
-        _chk(lib().talc_table_build(dump.encode(), junctions.encode() if junctions else None, C.byref(params), C.byref(h), st.ctypes.data))
+        if device is None:
+            _chk(lib().talc_table_build(dump.encode(), junctions.encode() if junctions else None, C.byref(params), C.byref(h), st.ctypes.data))
+        else:
+            _chk(lib().talc_table_build_device(dump.encode(), junctions.encode() if junctions else None, C.byref(params),
+                                               int(device), C.byref(h), st.ctypes.data))
         t = cls(h, params)
         t.build_stats = st
         return t

@@ -370,3 +370,44 @@ def test_mixed_lengths_config5_shape():
     so, st = _check(pair, 0, 120)
     lens = [len(s) for s in so]
     assert max(lens) > 3000 and min(l for l in lens if l > 31) < 1500
+
+
+# ---------------------------------------------------------------- device table builder
+def test_device_built_table_equals_host_built_table(tmp_path):
+    """talc_table_from_arrays_device / talc_table_build_device against the host builder on the same dump: same size,
+    and the same answer for every stored k-mer (duplicates with different counts included: first wins), for k-mers
+    that are not stored, after junction colouring and homopolymer de-colouring, and through the text parser."""
+    from talc_amd.synth import Synth
+    S = Synth(target_kmers=400_000, k=21, seed=41)
+    keys, counts = S.dump_arrays()
+    rng = np.random.default_rng(3)
+    # duplicate 5000 entries with other counts somewhere later in the dump, and some below min_count earlier
+    dup = rng.integers(0, len(keys), 5000)
+    keys2 = np.concatenate([keys[dup[:500]], keys, keys[dup]])
+    counts2 = np.concatenate([np.ones(500, np.uint32), counts, (counts[dup] + 7).astype(np.uint32)])
+    p = T.default_params(k=21, use_junctions=1)
+    th = T.Table.from_arrays(keys2, counts2, p)
+    td = T.Table.from_arrays(keys2, counts2, p, device=0)
+    assert len(th) == len(td) > 0
+    jk, jc = S.junction_arrays()
+    for t in (th, td):
+        t.colour(jk, jc)
+        t.decolour_repeats()
+    q = np.concatenate([keys2, rng.integers(0, 1 << 42, 50000, dtype=np.uint64)])
+    hc, hj = th.lookup_host(q)
+    dc, dj = td.lookup_host(q)
+    assert (hc == dc).all() and (hj == dj).all()
+    td.upload(0)
+    gc, gj = td.lookup(q)
+    assert (gc == hc).all() and (gj == hj).all()
+    # through the text parser
+    dump = str(tmp_path / "d.txt")
+    S.write_dump(dump)
+    junc = str(tmp_path / "j.txt")
+    S.write_junctions(junc)
+    fh = T.Table.from_files(dump, junc, p)
+    fd = T.Table.from_files(dump, junc, p, device=0)
+    assert len(fh) == len(fd) and (fh.build_stats == fd.build_stats).all()
+    a = fh.lookup_host(q)
+    b = fd.lookup_host(q)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
