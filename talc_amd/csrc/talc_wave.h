@@ -378,178 +378,6 @@ TALC_D void wave_edit_lcs_reg(const uint8_t* __restrict__ H_, int n, const uint8
   lcsLen = lane_get(resL, ln);
 }
 
-// ------------------------------------------------------------------ x-drop, band held in registers
-// Same algorithm as wave_xdrop, for live bands of at most 64*NR cells: each of the three
-// anti-diagonals lives in NR registers per lane (ring position = column mod 64*NR; lane = position
-// mod 64, register = position / 64), neighbours come by a one-lane rotation (DPP), the band
-// trimming by ballots + scalar bit scans; the inner computation is branch-free; no memory traffic
-// and no barrier inside the loop.  The two segments are staged into `stage` (LDS).
-// Returns 1 if the seed moves, 0 if not, -1 if the band outgrew 64*NR cells or the segments do not
-// fit the stage (the caller then retries with a larger NR / the array version).
-TALC_D unsigned long long rot_to_idx(unsigned long long mask, int off) {
-  const int s = off & 63;
-  return s ? ((mask >> s) | (mask << (64 - s))) : mask;
-}
-// bits [from, from+64) (ring order, modulo 64*NR) of the ring bitmap B[NR]
-template <int NR>
-TALC_D unsigned long long ring_word(const unsigned long long (&B)[NR], int from) {
-  const int s = from & 63, w = (from >> 6) % NR, w1 = (w + 1) % NR;
-  unsigned long long lo = B[0], hi = B[0];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) { if (k == w) lo = B[k]; if (k == w1) hi = B[k]; }
-  return s ? ((lo >> s) | (hi << (64 - s))) : lo;
-}
-
-template <int NR>
-TALC_D int wave_xdrop_reg(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int match,
-                          int mismatch, int gapCost, int scoreDropOff, uint8_t TALC_AS3* stage, int stageCap, int& extCols,
-                          int& extRows, unsigned long long& cells, int& ndiag, int& extScore) {
-  constexpr int M = 64 * NR;
-  gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
-  const int l = lane_id();
-  qlen = uni(qlen); dlen = uni(dlen); scoreDropOff = uni(scoreDropOff); gapCost = uni(gapCost); match = uni(match); mismatch = uni(mismatch);
-  const int cols = qlen + 1, rows = dlen + 1;
-  extCols = extRows = 0;
-  if (rows == 1 || cols == 1) return 0;
-  const int undef = INT_MIN - gapCost;
-  if (qlen + dlen + 16 > stageCap) return -1;   // segments do not fit the LDS stage: slow path
-  const int qpad = (qlen + 7) & ~7;
-  for (int i = l; i < qlen; i += 64) stage[i] = querySeg[i];
-  for (int i = l; i < dlen; i += 64) stage[qpad + i] = dbSeg[i];
-  WSYNC();
-  const uint8_t TALC_AS3* q = stage;
-  const uint8_t TALC_AS3* d = stage + qpad;
-  const int g0 = (-gapCost > scoreDropOff) ? undef : gapCost;
-  int r1[NR], r2[NR], r3[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) { r1[k] = undef; r2[k] = undef; r3[k] = undef; }
-  r2[0] = (l == 0) ? 0 : undef;        // antiDiag2 = [0]      (column 0)
-  r3[0] = (l <= 1) ? g0 : undef;       // antiDiag3 = [g, g]   (columns 0, 1)
-  int len1 = 0, len2 = 1, len3 = 2, off1 = 0, off2 = 0, off3 = 0;
-  int minCol = 1, maxCol = 2, adn = 1, best = 0;
-  unsigned long long ncell = 0;
-  while (minCol < maxCol) {
-    ++adn;
-    len1 = len2; len2 = len3;
-    off1 = off2; off2 = off3; off3 = minCol - 1;
-    len3 = maxCol + 1 - off3;
-    if (len3 > M) return -1;
-    const int minScore = best - scoreDropOff;
-    const int border = adn * gapCost;
-    const int b0 = (off3 == 0 && border > minScore) ? border : undef;        // first column
-    const int bN = (adn == maxCol && border > minScore) ? border : undef;    // first row
-    int rot2[NR], rot1[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) { r1[k] = r2[k]; r2[k] = r3[k]; }
-#pragma unroll
-    for (int k = 0; k < NR; ++k) { rot2[k] = lane_ror1(r2[k]); rot1[k] = lane_ror1(r1[k]); }
-    unsigned long long Bm[NR], BM[NR];
-    int cand = INT_MIN;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const int kp = (k + NR - 1) % NR;
-      const int left2 = (NR > 1 && l == 0) ? rot2[kp] : rot2[k];   // antiDiag2[col-1]
-      const int diag1 = (NR > 1 && l == 0) ? rot1[kp] : rot1[k];   // antiDiag1[col-1]
-      const int own2 = r2[k];                                      // antiDiag2[col]
-      const int idx = (64 * k + l - off3) & (M - 1);
-      const int col = off3 + idx;
-      const int qi = min(max(col - 1, 0), qlen - 1), di = min(max(adn - col - 1, 0), dlen - 1);
-      const int sc = (q[qi] == d[di]) ? match : mismatch;
-      const int tmp = max(max(left2, own2) + gapCost, diag1 + sc);
-      const bool interior = (idx >= 1) & (idx < len3 - 1);
-      int nv = (interior & (tmp >= minScore)) ? tmp : undef;
-      if (match > 0) cand = max(cand, nv);
-      nv = (idx == 0) ? b0 : nv;
-      nv = (idx == len3 - 1) ? bN : nv;
-      r3[k] = nv;
-      const bool u3 = (nv == undef);
-      Bm[k] = ballot64((idx >= 1) & (idx < len3) & u3 & (col - off2 - 1 < len2) & (left2 == undef));
-      BM[k] = ballot64((idx <= len3 - 2) & u3 & (own2 == undef));
-    }
-    ncell += (unsigned long long)(maxCol - minCol);
-    // with match <= 0 no cell can exceed the initial best (0): the reduction is only needed otherwise
-    if (match > 0) best = max(best, max(border, wave_max_i32(cand)));
-    // ---- band trimming: count undefined cells from idx 1 upwards / from idx len3-2 downwards
-    int t1 = 0;
-    {
-      int pos = off3 + 1, left = len3;   // at most len3-1 cells can be trimmed, pm is false beyond anyway
-      while (left > 0) {
-        const unsigned long long w = ring_word<NR>(Bm, pos);
-        const int run = (int)__ffsll((long long)~w) - 1;   // 0..64 (ffsll(0) = 0 -> -1 cannot happen: ~w == 0 only if w all ones)
-        const int r = (~w == 0ull) ? 64 : run;
-        t1 += r;
-        if (r < 64) break;
-        pos += 64; left -= 64;
-      }
-    }
-    minCol += uni(t1);
-    int t2 = 0;
-    {
-      const int top = len3 - 2;          // idx of the first candidate, going down to idx 0
-      int hiIdx = top;
-      while (hiIdx >= 0) {
-        // word holding idx (hiIdx-63 .. hiIdx), bit 63 = idx hiIdx
-        const unsigned long long w = ring_word<NR>(BM, off3 + hiIdx - 63 + M);
-        // idx below 0 are not candidates: mask them out (they read as zero = stop)
-        const int valid = min(hiIdx + 1, 64);
-        const unsigned long long wm = (valid == 64) ? w : (w & (~0ull << (64 - valid)));
-        const unsigned long long nw = ~wm;
-        const int run = nw ? (int)__clzll((long long)nw) : 64;
-        t2 += run;
-        if (run < 64) break;
-        hiIdx -= 64;
-      }
-      t2 = min(t2, top + 1);
-    }
-    maxCol -= uni(t2);
-    ++maxCol;
-    minCol = max(minCol, adn + 2 - rows);
-    maxCol = min(maxCol, cols);
-  }
-  cells += ncell;
-  ndiag = adn;
-  // value of antiDiag[col] for a wave-uniform col
-  auto pick = [&](const int (&r)[NR], int col) -> int {
-    const int slot = ((col & (M - 1)) >> 6);
-    int v = r[0];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) if (k == slot) v = r[k];
-    return lane_get(v, col & 63);
-  };
-  int lcol = len3 + off3 - 2;
-  int lrow = adn - lcol;
-  int lscore = pick(r3, lcol);
-  if (lscore == undef) {
-    const int a = pick(r2, off2 + len2 - 2);
-    if (a != undef) { lcol = len2 + off2 - 2; lrow = adn - 1 - lcol; lscore = a; }
-    else if (len2 > 2) {
-      const int b = pick(r2, off2 + len2 - 3);
-      if (b != undef) { lcol = len2 + off2 - 3; lrow = adn - 1 - lcol; lscore = b; }
-    }
-  }
-  if (lscore == undef) {
-    // general case: first maximum of antiDiag1
-    int v = INT_MIN;
-    unsigned long long dummy = 0; (void)dummy;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) { const int idx1 = (64 * k + l - off1) & (M - 1); if (idx1 < len1) v = max(v, r1[k]); }
-    const int mx = wave_max_i32(v);
-    if (mx > undef) {
-      unsigned long long Bq[NR];
-#pragma unroll
-      for (int k = 0; k < NR; ++k) { const int idx1 = (64 * k + l - off1) & (M - 1); Bq[k] = ballot64((idx1 < len1) && (r1[k] == mx)); }
-      int i = 0;
-      for (int base = 0; base < len1; base += 64) {
-        const unsigned long long w = ring_word<NR>(Bq, off1 + base);
-        if (w) { i = base + (int)__ffsll((long long)w) - 1; break; }
-      }
-      lscore = mx; lcol = i + off1; lrow = adn - 2 - lcol;
-    }
-  }
-  if (lscore != undef) { extCols = lcol; extRows = lrow; extScore = lscore; return 1; }
-  return 0;
-}
-
 // ------------------------------------------------------------------ x-drop as a wavefront recurrence
 // The unit-cost x-drop extension (match 0, mismatch -1, gap -1 — the only scoring the correction path
 // extends seeds with) computed as furthest-reaching points, one diagonal per lane (NR diagonals per
