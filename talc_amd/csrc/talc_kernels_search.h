@@ -61,7 +61,7 @@ struct SearchCaps {
   uint32_t weakPool;    // bytes for corrected weak sequences
   uint64_t slotBytes;
   uint64_t o_setA, o_setB, o_seqPool, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
-      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak, o_xring;
+      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak;
 };
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
@@ -115,7 +115,6 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   c.o_wOff = take((uint64_t)c.regCap * 4);
   c.o_wLen = take((uint64_t)c.regCap * 4);
   c.o_weak = take(c.weakPool);
-  c.o_xring = take(2ull * 3 * 256 * 4);   // resumable x-drop levels (XD_RING_POS diagonals x 3 levels x {F, E})
   c.slotBytes = align_up(o, 256);
   return c;
 }
@@ -434,7 +433,6 @@ __shared__ uint64_t g_aimK[AIMS_LDS], g_aimN[AIMS_LDS];
 __shared__ uint32_t g_aimPos[AIMS_LDS];             // first AIMS_LDS target anchors
 __shared__ unsigned long long g_bloom[64];          // 4096-bit k-mer Bloom filter of the current search
 __shared__ int g_dp[3 * LDS_DP_CAP];                // x-drop stage / short DP arrays
-__shared__ XdCache g_xc;                            // resumable x-drop wavefront of the Trail extended last (edges)
 
 struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online (findBestBORDER is a fold)
   bool have; double score; double dist; double idscore; uint32_t len; uint32_t lanc, ranc;
@@ -457,7 +455,6 @@ struct Wv {
   uint8_t* seqPool;                 // NBUF buffers of seqCap bytes
   unsigned long long freeMask[NBUF / 64];   // wave-uniform free bitmap of the pool
   uint8_t *ref, *fullPool, *edgeLong, *edgeShort, *edgeTmp, *weak;
-  int* xring;                       // resumable x-drop levels (wave_xdrop_wfa)
   AnchorRec *ancL, *ancR; uint32_t* ancPos;
   FullMeta* fullMeta;
   int *dpG;   // 3 x dpCap ints in HBM
@@ -619,11 +616,9 @@ TALC_D int pool_alloc() {
     }
   }
   if (id < 0) { X.overflow |= OVF_TRAILS; id = 0; }
-  if (g_xc.buf == id) g_xc.valid = 0;   // (every lane writes the same value)
   return id;
 }
 TALC_D void pool_free(uint32_t id) {
-  if (g_xc.buf == (int)id) g_xc.valid = 0;
 #pragma unroll
   for (int w = 0; w < NBUF / 64; ++w) if ((int)(id >> 6) == w) X.freeMask[w] |= (1ull << (id & 63));
 }
@@ -805,7 +800,7 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 // growth-order restatement: the seed sits at the anchor end; extension starts at offset S
 // (K-1 walking RIGHT: Seed(0,0,K-1,K-1); K walking LEFT: Seed(len-K, len-K, len-1, len-1)).
 TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
-                                  bool withScore, int cacheBuf = -1) {
+                                  bool withScore) {
   PROF_DECL;
   refLen = uni(refLen); candLen = uni(candLen); xdrop = uni(xdrop); ref = uni_ptr(ref); cand = uni_ptr(cand);
   const int K = (int)X.P.K;
@@ -825,12 +820,9 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
     uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
     // furthest-reaching wavefronts, 1 / 2 / 4 diagonals per lane (x up to 31 / 63 / 127)
     const int ndiagonals = min(max(xdrop, 0), qlen) + min(max(xdrop, 0), dlen) + 1;
-    // (the resumable state is kept for the Trail's own sequence as the query against the search's reference)
-    const int cb = (state || cacheBuf >= NBUF) ? uni(cacheBuf) : -1;   // (a Trail's buffer: only as the query; reshape: either way)
-    XdCache TALC_AS3* xc = (XdCache TALC_AS3*)&g_xc;
-    if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, xc, cb, X.xring);
-    else if (ndiagonals <= 127) rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, xc, cb, X.xring);
-    else if (ndiagonals <= 255) rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, xc, cb, X.xring);
+    if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (ndiagonals <= 127) rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (ndiagonals <= 255) rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
     else rc = -1;
     if (rc < 0) {   // band wider than a wavefront (x-drop above ~30): anti-diagonals in LDS, or in HBM when too long
       const int need = qlen + 3;
@@ -880,7 +872,7 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
 TALC_DN bool trail_seed_and_extend(int set, int t, int len, int xdrop) {
   WSYNC();   // the Trail's last bases were appended by lane 0: make them visible to the DP lanes
   TrailRec r = tr_get(set, t);
-  const SeedExt e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)r.buf * X.C.seqCap, len, xdrop, true, (int)r.buf);
+  const SeedExt e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)r.buf * X.C.seqCap, len, xdrop, true);
   const bool ok1 = (e.lenHistExt == len);
   r.fail = ok1 ? 0u : r.fail + 1u;
   r.score = e.score;
@@ -915,14 +907,12 @@ TALC_DN void record_edge(int set, int t, int len0) {
   // findStopPosition(A, B): `reference` = A, `shorterPath` = B
   const uint8_t* A = shorter ? X.ref : path; const int lenA = shorter ? (int)X.refLen : len;
   const uint8_t* Bq = shorter ? path : X.ref; const int lenB = shorter ? len : (int)X.refLen;
-  g_xc.valid = 0;   // reshape extends ONE pair with x, x-1, x-2, ...: its own key in the resumable-wavefront ring
-  LSYNC();
-  nxt = seed_and_extension(A, lenA, Bq, lenB, xdrop1, false, NBUF);
+  nxt = seed_and_extension(A, lenA, Bq, lenB, xdrop1, false);
   bool goFurther = true;
   do {
     --xdrop1;
     cur = nxt;
-    nxt = seed_and_extension(A, lenA, Bq, lenB, xdrop1, false, NBUF);
+    nxt = seed_and_extension(A, lenA, Bq, lenB, xdrop1, false);
     if (nxt.lenHistExt < cur.lenHistExt) goFurther = false;
   } while (goFurther & (xdrop1 > 0));
   // score of the retained extension (Trail.cpp:408-434)
@@ -1474,7 +1464,6 @@ TALC_D void init_first_trail(const AnchorRec& a) {
   const uint32_t b0 = (uint32_t)pool_alloc();
   wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
   g_bloom[lane_id()] = 0ull;
-  g_xc.valid = 0;   // new reference
   LSYNC();
   bloom_query_insert(a.kmer, a.nmask);
   if (lane_id() == 0) {
@@ -1719,12 +1708,11 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.regS = (uint32_t*)(slot + C.o_regS); X.regE = (uint32_t*)(slot + C.o_regE);
   X.wOff = (uint32_t*)(slot + C.o_wOff); X.wLen = (uint32_t*)(slot + C.o_wLen);
   X.weak = slot + C.o_weak;
-  X.xring = (int*)(slot + C.o_xring);
   X.trace = trace;
   unsigned long long totCells = 0, totSteps = 0;
   PROF_DECL2;
 #ifdef TALC_PROF
-  if (l == 0) { for (int i = 0; i < PF_N; ++i) g_prof[i] = 0; for (int i = 0; i < 4; ++i) g_prof_x[i] = 0; }
+  if (l == 0) for (int i = 0; i < PF_N; ++i) g_prof[i] = 0;
   const unsigned long long _pf_k0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -1884,7 +1872,6 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
 #ifdef TALC_PROF
     g_prof[PF_TOTAL] = __builtin_amdgcn_s_memtime() - _pf_k0;
     for (int i = 0; i < PF_N; ++i) atomicAdd((unsigned long long*)&counters[2 + i], g_prof[i]);
-    for (int i = 0; i < 4; ++i) atomicAdd((unsigned long long*)&counters[2 + PF_N + i], g_prof_x[i]);
 #endif
   }
 }

@@ -15,16 +15,7 @@
 namespace talc {
 
 #define WSYNC() __syncthreads()   /* one wave per workgroup: orders the wave's own LDS/global traffic */
-#define LSYNC_WAVE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-#ifdef TALC_PROF
-__shared__ unsigned long long g_prof_x[4];   // x-drop phases: staging, levels, selection, calls
-#define XPROF_T() __builtin_amdgcn_s_memtime()
-#define XPROF_ADD(i, t0) do { if ((threadIdx.x & 63u) == 0) g_prof_x[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
-#else
-#define XPROF_T() 0ull
-#define XPROF_ADD(i, t0) ((void)0)
-#endif
 TALC_D int lane_id() { return (int)(threadIdx.x & 63u); }
 TALC_D int wave_max_i32(int v) {
 #pragma unroll
@@ -400,18 +391,10 @@ TALC_D unsigned long long lds_load_u64(const uint8_t TALC_AS3* p) {
   return v;
 }
 
-// Resumable wavefront (one diagonal per lane only).  A Trail is re-extended every CHECK_INTERVAL steps with its
-// path a few bases longer and everything else unchanged, and reshape (Trajectory.cpp:114-155) extends the same pair
-// again and again with x one smaller.  A level none of whose diagonals has reached the end of the query is the same
-// whatever lies beyond that end and whatever x is (below the final level, whose border rule depends on x), so the
-// last three such levels are kept and a later extension of the same pair starts from the highest one below its x.
-struct XdCache { int valid, buf, qlen, dlen; int lev[3], kmin[3], npos[3]; };   // ring of the last three such levels (header)
-constexpr int XD_RING_POS = 256;   // diagonals per stored level (4 per lane); the levels themselves live in HBM scratch
-
 template <int NR>
 TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int x,
                           uint8_t TALC_AS3* stage, int stageCap, int& extCols, int& extRows, int& extScore,
-                          unsigned long long& cells, XdCache TALC_AS3* cache = nullptr, int cacheBuf = -1, int* ring_ = nullptr) {
+                          unsigned long long& cells) {
   gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
   qlen = uni(qlen); dlen = uni(dlen); x = uni(x);
@@ -426,12 +409,10 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   const int qS = min(qlen, dlen + X), dS = min(dlen, qlen + X);
   const int qpad = (qS + 16) & ~7;
   if (qpad + dS + 16 > stageCap) return -1;
-  const unsigned long long _xt0 = XPROF_T(); (void)_xt0;
   for (int i = l; i < qS; i += 64) stage[i] = querySeg[i];
   for (int i = l; i < dS; i += 64) stage[qpad + i] = dbSeg[i];
   if (l == 0) { stage[qS] = 0xF0; stage[qpad + dS] = 0xF1; }   // differ from each other and from every base code
   WSYNC();
-  const unsigned long long _xt1 = XPROF_T(); (void)_xt1;
   const int bmax = x >= 2 ? x - 1 : (x == 1 ? 1 : 0);
   const int corner = qlen + dlen;
   int F[NR], E[NR], amax[NR], forb[NR];
@@ -464,35 +445,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
       }
     }
   };
-  const bool useCache = (NR <= 2) && (cache != nullptr) && (cacheBuf >= 0) && (ring_ != nullptr);
-  int TALC_AS1* ringF = (int TALC_AS1*)uni_ptr(ring_);                 // [3][XD_RING_POS] furthest points
-  int TALC_AS1* ringE = ringF + 3 * XD_RING_POS;                        // [3][XD_RING_POS] levels that reached them
-  int eStart = 1;
-  bool resumed = false;
-  if (useCache) {
-    const bool same = cache->valid && cache->buf == cacheBuf && cache->dlen == dlen && cache->qlen <= qlen;
-    if (!same) {
-      if (l == 0) { cache->valid = 1; cache->buf = cacheBuf; cache->dlen = dlen; cache->lev[0] = cache->lev[1] = cache->lev[2] = -1; }
-    } else {
-      int best = -1, bl = 0;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) { const int lv = cache->lev[r]; if (lv >= 1 && lv < x && lv > bl) { bl = lv; best = r; } }
-      if (best >= 0) {
-        const int shift = kmin - cache->kmin[best], np = cache->npos[best];   // same diagonal in the stored layout
-#pragma unroll
-        for (int s2 = 0; s2 < NR; ++s2) {
-          const int j = 64 * s2 + l, jo = j + shift;
-          const bool in = (jo >= 0) & (jo < np) & (j < nd);
-          const int cf = ringF[best * XD_RING_POS + (in ? jo : 0)], cE = ringE[best * XD_RING_POS + (in ? jo : 0)];
-          F[s2] = in ? cf : NEG; E[s2] = in ? cE : 0;
-        }
-        eStart = bl + 1; resumed = true;
-      }
-    }
-    if (l == 0) cache->qlen = qlen;
-    LSYNC_WAVE();
-  }
-  if (!resumed) {
+  {
     int a0[NR]; bool act0[NR];
     const int j0 = -kmin;
 #pragma unroll
@@ -501,15 +454,6 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 #pragma unroll
     for (int s = 0; s < NR; ++s) if (64 * s + l == j0) F[s] = a0[s];
   }
-  // levels (below x) no diagonal of which has reached the end of the query go to the ring
-  bool clean = useCache;
-  auto touchesQueryEnd = [&]() -> bool {
-    bool t = false;
-#pragma unroll
-    for (int s2 = 0; s2 < NR; ++s2) t |= (F[s2] >= 0) && (((F[s2] + kmin + 64 * s2 + l) >> 1) >= qlen);
-    return ballot64(t) != 0ull;
-  };
-  if (clean && !resumed) { clean = !touchesQueryEnd(); }
   bool cornerHit = false;
   int cornerE = 0;
   {
@@ -519,7 +463,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     cornerHit = hit != 0ull;
   }
   unsigned long long work = 0;
-  for (int e = eStart; e <= x && !cornerHit; ++e) {
+  for (int e = 1; e <= x && !cornerHit; ++e) {
     int rotR[NR], rotL[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) { rotR[s] = lane_ror1(F[s]); rotL[s] = lane_rol1(F[s]); }
@@ -552,24 +496,8 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     }
     work += (unsigned long long)min(nd, 2 * e + 1);
     if (hit != 0ull) { cornerHit = true; cornerE = e; }
-    if (clean && e < x) {
-      clean = !touchesQueryEnd();
-      if (clean) {
-        const int r = e % 3;
-#pragma unroll
-        for (int s2 = 0; s2 < NR; ++s2) { ringF[r * XD_RING_POS + 64 * s2 + l] = F[s2]; ringE[r * XD_RING_POS + 64 * s2 + l] = E[s2]; }
-        if (l == 0) { cache->lev[r] = e; cache->kmin[r] = kmin; cache->npos[r] = 64 * NR; }
-      }
-    }
   }
-  if (useCache) WSYNC();   // ring stores (HBM) before any later read by other lanes
   cells += work;
-  XPROF_ADD(1, _xt1);
-#ifdef TALC_PROF
-  if (l == 0) { const unsigned long long nl = (unsigned long long)((cornerHit ? cornerE : x) - eStart + 1 > 0 ? (cornerHit ? cornerE : x) - eStart + 1 : 0);
-    if (NR > 1) g_prof_x[3] += nl; else if (resumed) g_prof_x[2] += nl; else g_prof_x[0] += nl; }
-#endif
-  const unsigned long long _xt2 = XPROF_T(); (void)_xt2;
   if (cornerHit) { extCols = qlen; extRows = dlen; extScore = -cornerE; return 1; }
   // ---- where the anti-diagonal loop of the original stops, and the cell it reports (talc_wfa.h)
   int mF = NEG;
