@@ -41,7 +41,6 @@ def parse():
     ap.add_argument("--cpu-backend", choices=["flat", "map"], default="flat",
                     help="oracle table: flat hash (quick to build) or the reference's std::map")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--check", type=int, default=0, help="also compare this many reads with the oracle")
     return ap.parse_args()
 
 
