@@ -22,6 +22,10 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -150,45 +154,69 @@ void setBasicReadStatsHeader(const std::string& statFile) {
        "CorrHead?\tCorrHeadLen\tCorrTail?\tCorrTailLen\tCorrlength\tnbInKmers2\n";
 }
 
-// io.cpp:26-48 with SeqFileIn::readRecords semantics: FASTA ('>') or FASTQ ('@') decided by the first
-// record; id = the whole header line after the marker; multi-line sequences concatenated; qualities dropped.
-// Sequences are kept as raw text: the device applies the Dna5 conversion.
-bool loadSeqData(const std::string& file, std::vector<std::string>& ids, std::string& bases, std::vector<uint64_t>& offsets) {
-  std::ifstream in(file);
-  if (!in) { std::cerr << "ERROR: Could not open file " << file << "\n"; return false; }
-  auto chomp = [](std::string& l) { while (!l.empty() && (l.back() == '\r' || l.back() == '\n')) l.pop_back(); };
-  std::string line;
-  bool started = false, fastq = false, have = false;
-  offsets.assign(1, 0);
-  while (std::getline(in, line)) {
-    chomp(line);
-    if (!started) {
-      if (line.empty()) continue;
-      started = true;
-      fastq = line[0] == '@';
-      if (!fastq && line[0] != '>') return false;
-    }
-    if (fastq) {
-      if (line.empty()) continue;
-      if (line[0] != '@') return false;
-      ids.push_back(line.substr(1));
-      const size_t start = bases.size();
-      while (std::getline(in, line)) { chomp(line); if (!line.empty() && line[0] == '+') break; bases += line; }
-      const size_t want = bases.size() - start;
-      size_t got = 0;
-      while (got < want && std::getline(in, line)) { chomp(line); got += line.size(); }
-      offsets.push_back(bases.size());
-    } else if (!line.empty() && line[0] == '>') {
-      if (have) offsets.push_back(bases.size());
-      ids.push_back(line.substr(1));
-      have = true;
-    } else if (have) {
-      bases += line;
+// Streaming FASTA / FASTQ reader (replaces loadSeqData, io.cpp:26-48, which holds the whole file, main.cpp:209-211):
+// the format is decided by the first non-empty line ('>' or '@'); id = the whole header line after the marker;
+// multi-line sequences are concatenated; FASTQ qualities are skipped by length.  Sequences are kept as raw text:
+// the device applies the Dna5 conversion.
+class SeqReader {
+ public:
+  explicit SeqReader(const std::string& file) : in_(file) {
+    if (!in_) { std::cerr << "ERROR: Could not open file " << file << "\n"; ok_ = false; return; }
+    while (std::getline(in_, line_)) {   // first non-empty line decides the format
+      chomp(line_);
+      if (line_.empty()) continue;
+      fastq_ = line_[0] == '@';
+      if (!fastq_ && line_[0] != '>') ok_ = false;
+      pending_ = true;
+      break;
     }
   }
-  if (!fastq && have) offsets.push_back(bases.size());
-  return true;
-}
+  bool ok() const { return ok_; }
+  // next record; false at the end of the file (or on a malformed FASTQ header: bad() then says so)
+  bool next(std::string& id, std::string& seq) {
+    seq.clear();
+    if (!ok_) return false;
+    if (!pending_) {
+      while (true) {
+        if (!std::getline(in_, line_)) return false;
+        chomp(line_);
+        if (fastq_ ? !line_.empty() : (!line_.empty() && line_[0] == '>')) break;
+      }
+    }
+    pending_ = false;
+    if (fastq_) {
+      if (line_[0] != '@') { ok_ = false; return false; }
+      id = line_.substr(1);
+      while (std::getline(in_, line_)) { chomp(line_); if (!line_.empty() && line_[0] == '+') break; seq += line_; }
+      size_t got = 0;
+      while (got < seq.size() && std::getline(in_, line_)) { chomp(line_); got += line_.size(); }
+      return true;
+    }
+    id = line_.substr(1);
+    while (std::getline(in_, line_)) {
+      chomp(line_);
+      if (!line_.empty() && line_[0] == '>') { pending_ = true; break; }
+      seq += line_;
+    }
+    return true;
+  }
+
+ private:
+  static void chomp(std::string& l) { while (!l.empty() && (l.back() == '\r' || l.back() == '\n')) l.pop_back(); }
+  std::ifstream in_;
+  std::string line_;
+  bool ok_ = true, fastq_ = false, pending_ = false;
+};
+
+// One batch of reads on its way through the pipeline: read -> corrected on a device -> written, in input order.
+struct Chunk {
+  uint64_t index = 0;
+  std::vector<std::string> ids;
+  std::string bases;
+  std::vector<uint64_t> offsets{0};
+  std::vector<std::string> out;
+  std::vector<int32_t> status;
+};
 
 double secs(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
   return std::chrono::duration<double>(b - a).count();
@@ -211,15 +239,19 @@ int main(int argc, const char** argv) {
 
   auto t0 = std::chrono::steady_clock::now();
   std::cout << "[TALC]: Attempting to load sequences." << std::endl;
-  std::vector<std::string> ids;
-  std::string bases;
-  std::vector<uint64_t> offsets;
-  if (!loadSeqData(o.seqFile, ids, bases, offsets)) {  // main.cpp:219,323: prints and falls off main
-    std::cout << "[TALC]: ISSUE WITH INPUT FILES" << std::endl;
-    return 0;
+  // first pass: format check and record count only (the reads themselves stream through in batches below)
+  uint64_t nReadsTotal = 0;
+  {
+    SeqReader probe(o.seqFile);
+    std::string id, seq;
+    if (probe.ok()) while (probe.next(id, seq)) ++nReadsTotal;
+    if (!probe.ok()) {  // main.cpp:219,323: prints and falls off main
+      std::cout << "[TALC]: ISSUE WITH INPUT FILES" << std::endl;
+      return 0;
+    }
   }
   std::cout << "[TALC]: Hmm...it seems the sequence file is OK." << std::endl;
-  std::cout << "[TALC]: " << ids.size() << " long read(s) loaded" << std::endl;
+  std::cout << "[TALC]: " << nReadsTotal << " long read(s) loaded" << std::endl;
   auto t1 = std::chrono::steady_clock::now();
 
   talc_table* table = nullptr;
@@ -233,13 +265,9 @@ int main(int argc, const char** argv) {
                  ? talc_table_build_device(o.dump.c_str(), o.useJ ? o.jdump.c_str() : nullptr, &o.p, 0, &table, st)
                  : talc_table_build(o.dump.c_str(), o.useJ ? o.jdump.c_str() : nullptr, &o.p, &table, st);
     if (rc != TALC_OK) {
-      if (rc == TALC_ERR_IO) {
-        // an unreadable dump leaves the reference with an empty map (Jellyfish.cpp:249-251)
-        std::cerr << "talc: " << talc_last_error() << "\n";
-      } else {
-        std::cerr << "talc: " << talc_last_error() << "\n";
-        return 2;
-      }
+      // an unreadable dump leaves the reference with an empty map (Jellyfish.cpp:249-251); anything else is fatal
+      std::cerr << "talc: " << talc_last_error() << "\n";
+      if (rc != TALC_ERR_IO) return 2;
     } else {
       tableSize = talc_table_size(table);
       std::cout << "There were " << st[0] << " k-mers retrieved from database." << std::endl;
@@ -258,106 +286,122 @@ int main(int argc, const char** argv) {
   std::cout << "[TALC]: Good news, there are nodes in the de Bruijn Graph." << std::endl;
   std::cout << "[TALC]: Maybe we can try and correct some long reads, then?" << std::endl;
 
-  const uint32_t nReads = (uint32_t)ids.size();
-  std::vector<std::string> outSeqs(nReads);
-  std::vector<int32_t> status(nReads, TALC_READ_SKIPPED_SHORT);
-  bool failed = false;
-  std::string failMsg;
-  if (emptyRun) {
-    // no table at all: pass-through with the reference's statuses (Dna5 conversion / -rev still apply)
-    for (uint32_t r = 0; r < nReads; ++r) {
-      std::string s = bases.substr(offsets[r], offsets[r + 1] - offsets[r]);
-      for (auto& c : s) { c = (c == 'a' || c == 'A') ? 'A' : (c == 'c' || c == 'C') ? 'C' : (c == 'g' || c == 'G') ? 'G' : (c == 't' || c == 'T') ? 'T' : 'N'; }
-      if (o.p.reverse) {
-        std::string rcs(s.size(), 'N');
-        for (size_t i = 0; i < s.size(); ++i) { char c = s[s.size() - 1 - i]; rcs[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
-        s = rcs;
-      }
-      status[r] = s.size() > o.p.k ? TALC_READ_NO_SOLID_KMER : TALC_READ_SKIPPED_SHORT;
-      outSeqs[r] = s;
-    }
-  } else {
-    int ndev = talc_device_count();
+  int ndev = 0;
+  if (!emptyRun) {
+    ndev = talc_device_count();
     if (ndev <= 0) { std::cerr << "talc: no MI355X / HIP device visible; the correction path has no CPU fallback\n"; return 2; }
     if (o.gpus > 0) ndev = std::min(ndev, o.gpus);
-    ndev = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ndev, std::max<uint32_t>(nReads, 1)));
-    // contiguous blocks of reads balanced by bases
-    std::vector<uint32_t> bounds(ndev + 1, nReads);
-    bounds[0] = 0;
-    {
-      const uint64_t total = offsets[nReads];
-      uint32_t r = 0;
-      for (int d = 1; d < ndev; ++d) {
-        const uint64_t target = total / ndev * d;
-        while (r < nReads && offsets[r] < target) ++r;
-        bounds[d] = r;
-      }
-    }
     std::cout << "[TALC]: correcting on " << ndev << " GPU(s); k-mer table replicated (" << talc_table_device_bytes(table) / 1e9 << " GB each)" << std::endl;
-    for (int d = 0; d < ndev && !failed; ++d)
-      if (talc_table_upload(table, d) != TALC_OK) { failed = true; failMsg = talc_last_error(); }
-    std::vector<std::thread> workers;
-    std::vector<std::string> errs(ndev);
-    for (int d = 0; d < ndev && !failed; ++d) {
-      workers.emplace_back([&, d]() {
-        talc_ctx* ctx = nullptr;
-        if (talc_ctx_create(table, &o.p, d, &ctx) != TALC_OK) { errs[d] = talc_last_error(); return; }
-        for (uint32_t lo = bounds[d]; lo < bounds[d + 1]; lo += o.batchReads) {
-          const uint32_t hi = std::min<uint32_t>(bounds[d + 1], lo + o.batchReads);
-          const uint32_t n = hi - lo;
-          std::vector<uint64_t> boffs(n + 1);
-          for (uint32_t i = 0; i <= n; ++i) boffs[i] = offsets[lo + i] - offsets[lo];
-          talc_batch* b = nullptr;
-          if (talc_batch_create(ctx, bases.data() + offsets[lo], boffs.data(), n, &b) != TALC_OK) { errs[d] = talc_last_error(); break; }
-          int rc = talc_batch_correct(ctx, b);
-          if (rc != TALC_OK) errs[d] = talc_last_error();
-          const uint64_t total = talc_batch_corrected_bytes(b);
-          std::vector<char> buf(std::max<uint64_t>(total, 1));
-          std::vector<uint64_t> oo(n + 1);
-          if (talc_batch_fetch_corrected(ctx, b, buf.data(), total, oo.data(), status.data() + lo) != TALC_OK) { errs[d] = talc_last_error(); talc_batch_destroy(b); break; }
-          for (uint32_t i = 0; i < n; ++i) outSeqs[lo + i].assign(buf.data() + oo[i], oo[i + 1] - oo[i]);
-          talc_batch_destroy(b);
-        }
-        talc_ctx_destroy(ctx);
-      });
-    }
-    for (auto& w : workers) w.join();
-    for (auto& e : errs) if (!e.empty()) { failed = true; failMsg = e; }
+    for (int d = 0; d < ndev; ++d)
+      if (talc_table_upload(table, d) != TALC_OK) { std::cerr << "talc: device error: " << talc_last_error() << "\n"; talc_table_destroy(table); return 2; }
   }
+  std::cout << "Specified output file name: " << outFile << std::endl;
+  std::ofstream of(outFile, std::ios_base::trunc);
+  if (!of) { std::cerr << "ERROR: Could not open the file " << outFile << "\n"; return 2; }
+
+  // ---- the pipeline: batches of --batch-reads reads are read under a lock (input order = batch index), corrected by
+  // whichever worker took them (two workers per GPU, each with its own context and stream, so that one batch's
+  // transfers overlap the other's kernels), and written strictly in input order; at most one batch per worker is
+  // in memory.  Replaces the load-everything / OpenMP loop / write-everything of main.cpp:209-310.
+  SeqReader reader(o.seqFile);
+  std::mutex rdMu, wrMu;
+  uint64_t nextIndex = 0, nextToWrite = 0, basesTotal = 0;
+  std::map<uint64_t, std::unique_ptr<Chunk>> finished;
+  std::ofstream lf;
+  std::atomic<bool> failed{false};
+  std::string failMsg;
+  auto readChunk = [&]() -> std::unique_ptr<Chunk> {
+    std::lock_guard<std::mutex> g(rdMu);
+    std::unique_ptr<Chunk> c(new Chunk());
+    std::string id, seq;
+    while (c->ids.size() < o.batchReads && reader.next(id, seq)) {
+      c->ids.push_back(id);
+      c->bases += seq;
+      c->offsets.push_back(c->bases.size());
+    }
+    if (c->ids.empty()) return nullptr;
+    c->index = nextIndex++;
+    basesTotal += c->bases.size();
+    return c;
+  };
+  auto writeReady = [&](std::unique_ptr<Chunk> c) {   // io.cpp:50-75 + SeqFileOut FASTA writer, io.cpp:105-111 log lines
+    std::lock_guard<std::mutex> g(wrMu);
+    finished[c->index] = std::move(c);
+    while (!finished.empty() && finished.begin()->first == nextToWrite) {
+      Chunk& k = *finished.begin()->second;
+      for (size_t r = 0; r < k.ids.size(); ++r) {
+        const char* msg = k.status[r] == TALC_READ_NO_STRUCTURE ? "Unable to define convenient structure."       // main.cpp:290
+                          : k.status[r] == TALC_READ_NO_SOLID_KMER ? "No solid kmer could be found." : nullptr;  // main.cpp:294
+        if (msg) {
+          if (!lf.is_open()) lf.open(logFile, std::ios_base::app);
+          lf << "[Read: " << k.ids[r] << " ]: " << msg << std::endl;
+        }
+        of << '>' << k.ids[r] << '\n';   // '>' id, sequence wrapped at 70 columns
+        const std::string& q = k.out[r];
+        for (size_t p = 0; p < q.size(); p += 70) { of.write(q.data() + p, (std::streamsize)std::min<size_t>(70, q.size() - p)); of.put('\n'); }
+      }
+      finished.erase(finished.begin());
+      ++nextToWrite;
+    }
+  };
+  auto passThrough = [&](Chunk& c) {
+    // no table at all: pass-through with the reference's statuses (Dna5 conversion / -rev still apply)
+    const size_t n = c.ids.size();
+    c.out.resize(n); c.status.assign(n, TALC_READ_SKIPPED_SHORT);
+    for (size_t r = 0; r < n; ++r) {
+      std::string q = c.bases.substr(c.offsets[r], c.offsets[r + 1] - c.offsets[r]);
+      for (auto& ch : q) { ch = (ch == 'a' || ch == 'A') ? 'A' : (ch == 'c' || ch == 'C') ? 'C' : (ch == 'g' || ch == 'G') ? 'G' : (ch == 't' || ch == 'T') ? 'T' : 'N'; }
+      if (o.p.reverse) {
+        std::string rcs(q.size(), 'N');
+        for (size_t i = 0; i < q.size(); ++i) { char ch = q[q.size() - 1 - i]; rcs[i] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : 'N'; }
+        q = rcs;
+      }
+      c.status[r] = q.size() > o.p.k ? TALC_READ_NO_SOLID_KMER : TALC_READ_SKIPPED_SHORT;
+      c.out[r] = q;
+    }
+  };
+  auto worker = [&](int device) {
+    talc_ctx* ctx = nullptr;
+    if (device >= 0 && talc_ctx_create(table, &o.p, device, &ctx) != TALC_OK) { failMsg = talc_last_error(); failed = true; return; }
+    while (!failed) {
+      std::unique_ptr<Chunk> c = readChunk();
+      if (!c) break;
+      if (device < 0) {
+        passThrough(*c);
+      } else {
+        const uint32_t n = (uint32_t)c->ids.size();
+        c->out.resize(n); c->status.assign(n, TALC_READ_SKIPPED_SHORT);
+        talc_batch* b = nullptr;
+        if (talc_batch_create(ctx, c->bases.data(), c->offsets.data(), n, &b) != TALC_OK) { failMsg = talc_last_error(); failed = true; break; }
+        if (talc_batch_correct(ctx, b) != TALC_OK) { failMsg = talc_last_error(); failed = true; }
+        const uint64_t total = talc_batch_corrected_bytes(b);
+        std::vector<char> buf(std::max<uint64_t>(total, 1));
+        std::vector<uint64_t> oo(n + 1);
+        if (talc_batch_fetch_corrected(ctx, b, buf.data(), total, oo.data(), c->status.data()) != TALC_OK) { failMsg = talc_last_error(); failed = true; talc_batch_destroy(b); break; }
+        for (uint32_t i = 0; i < n; ++i) c->out[i].assign(buf.data() + oo[i], oo[i + 1] - oo[i]);
+        talc_batch_destroy(b);
+        if (failed) break;
+      }
+      writeReady(std::move(c));
+    }
+    if (ctx) talc_ctx_destroy(ctx);
+  };
+  {
+    std::vector<std::thread> workers;
+    if (emptyRun) workers.emplace_back(worker, -1);
+    else for (int d = 0; d < ndev; ++d) for (int w = 0; w < 2; ++w) workers.emplace_back(worker, d);
+    for (auto& w : workers) w.join();
+  }
+  of.close();
   auto t3 = std::chrono::steady_clock::now();
   if (failed) {
     std::cerr << "talc: device error: " << failMsg << "\n";
     if (table) talc_table_destroy(table);
     return 2;
   }
-  // log lines (io.cpp:105-111, appended), in input order
-  {
-    std::ofstream lf;
-    for (uint32_t r = 0; r < nReads; ++r) {
-      const char* msg = status[r] == TALC_READ_NO_STRUCTURE ? "Unable to define convenient structure."    // main.cpp:290
-                        : status[r] == TALC_READ_NO_SOLID_KMER ? "No solid kmer could be found." : nullptr;  // main.cpp:294
-      if (!msg) continue;
-      if (!lf.is_open()) lf.open(logFile, std::ios_base::app);
-      lf << "[Read: " << ids[r] << " ]: " << msg << std::endl;
-    }
-  }
-  // io.cpp:50-75 + SeqFileOut FASTA writer: '>' id, sequence wrapped at 70 columns
-  std::cout << "Specified output file name: " << outFile << std::endl;
-  {
-    std::ofstream of(outFile, std::ios_base::trunc);
-    if (!of) { std::cerr << "ERROR: Could not open the file " << outFile << "\n"; return 2; }
-    std::string chunk;
-    for (uint32_t r = 0; r < nReads; ++r) {
-      of << '>' << ids[r] << '\n';
-      const std::string& s = outSeqs[r];
-      for (size_t p = 0; p < s.size(); p += 70) { of.write(s.data() + p, (std::streamsize)std::min<size_t>(70, s.size() - p)); of.put('\n'); }
-    }
-  }
-  auto t4 = std::chrono::steady_clock::now();
   if (table) talc_table_destroy(table);
   std::cout << "[TALC]: Looks like we are done now." << std::endl;
-  double nb = (double)offsets[nReads];
-  fprintf(stderr, "[talc] load=%.3fs table=%.3fs correct=%.3fs (%.3g bases/s) write=%.3fs total=%.3fs\n", secs(t0, t1), secs(t1, t2),
-          secs(t2, t3), secs(t2, t3) > 0 ? nb / secs(t2, t3) : 0.0, secs(t3, t4), secs(t0, t4));
+  fprintf(stderr, "[talc] scan=%.3fs table=%.3fs read+correct+write=%.3fs (%.3g bases/s, %llu batches) total=%.3fs\n", secs(t0, t1),
+          secs(t1, t2), secs(t2, t3), secs(t2, t3) > 0 ? (double)basesTotal / secs(t2, t3) : 0.0, (unsigned long long)nextIndex, secs(t0, t3));
   return 0;
 }

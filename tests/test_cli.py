@@ -90,6 +90,36 @@ def test_cli_jellyfish2_mode_is_a_dead_path_like_the_reference(cli, data, tmp_pa
     assert fa[".log"].count(b"No solid kmer could be found.") == 60
 
 
+def test_cli_streaming_reader_formats_and_batches(cli, data, tmp_path):
+    """The streaming reader and the ordered batch writer, without a GPU (the pass-through of -qm jellyfish2 goes through
+    the same pipeline): FASTQ, FASTA wrapped at 60 columns with blank lines and CRLF, batches of 1, 7 and everything —
+    the records come out in input order and identical to the one-batch FASTA run."""
+    fa = (data / "reads.fa").read_text().splitlines()
+    wrapped = tmp_path / "wrapped.fa"
+    with open(wrapped, "w", newline="") as g:
+        g.write("\r\n")
+        for i in range(0, len(fa), 2):
+            g.write(fa[i] + "\r\n")
+            for p in range(0, len(fa[i + 1]), 60):
+                g.write(fa[i + 1][p:p + 60] + "\r\n")
+            g.write("\r\n")
+    base = ["-k", "21", "-SR", str(data / "sr.dump"), "-qm", "jellyfish2"]
+    ref = run(cli, [str(data / "reads.fa")] + base + ["-o", "one"], tmp_path)
+    assert ref.returncode == 0, ref.stderr
+    want = files(str(tmp_path / "one"))
+    assert want[".fa"].count(b">") == 60
+    for name, src, extra in (("fq", data / "reads.fq", ["--batch-reads", "7"]), ("wr", wrapped, ["--batch-reads", "1"]),
+                             ("b13", data / "reads.fa", ["--batch-reads", "13"])):
+        r = run(cli, [str(src)] + base + extra + ["-o", name], tmp_path)
+        assert r.returncode == 0, r.stderr
+        got = files(str(tmp_path / name))
+        assert got[".fa"] == want[".fa"] and got[".log"] == want[".log"], name
+    # a file that is neither FASTA nor FASTQ: the reference prints and leaves with 0 (main.cpp:219,323)
+    (tmp_path / "bad.txt").write_text("hello\nworld\n")
+    r = run(cli, [str(tmp_path / "bad.txt")] + base, tmp_path)
+    assert r.returncode == 0 and b"ISSUE WITH INPUT FILES" in r.stdout
+
+
 def test_cli_empty_table_aborts_with_exit_1(cli, data, tmp_path):
     (tmp_path / "empty.dump").write_text("ACGTACGTACGTACGTACGTA 1\n")     # below MIN_COUNT
     r = run(cli, [str(data / "reads.fa"), "-k", "21", "-SR", str(tmp_path / "empty.dump")], tmp_path)
