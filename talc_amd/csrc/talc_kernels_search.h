@@ -439,10 +439,9 @@ struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online 
 };
 
 enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
-       PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS, PF_NPASS, PF_NP1, PF_N };
+       PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
-                       "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
-                       "#ffpasses", "#ffp1"}
+                       "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps"}
 
 struct Wv {
   // kernel constants
@@ -1442,7 +1441,7 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
   flush();
   g_bloom[l] = ((unsigned long long)(uint32_t)bwHi << 32) | (uint32_t)bwLo;
   stepCounter_ = sc0 + (uint32_t)done;
-#ifdef TALC_PROF_FFSTAT
+#ifdef TALC_PROF
   if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (unsigned long long)done; }
 #endif
   if (done) {
