@@ -122,6 +122,11 @@ def test_table_from_dump_files_matches_oracle(tmp_path):
         f.write("acgtacgtacgtacgtacgta 12\n")   # lower case is accepted by Dna5
         f.write("ACGT 5\n")                     # wrong length
         f.write("lonely\n")                     # one token: 'Error when building dBG...'
+        f.write("\n")                           # blank line
+        f.write("  GATTACAGATTACAGATTACA\t\t 41  trailing words\r\n")   # tabs, leading blanks, CRLF, extra tokens
+        f.write("TTTTACAGATTACAGATTACA 7x\n")    # atoi stops at the first non-digit: 7
+        f.write("CCCCACAGATTACAGATTACA +3\n")    # explicit sign
+        f.write("AAAAACAGATTACAGATTACA 5")       # last line without a newline
     p, q = PU.both_params(k=21, use_junctions=1)
     ot = O.OracleTable(q, O.OracleTable.MAP)
     st_o = ot.build_from_files(dump, jd)
@@ -134,6 +139,11 @@ def test_table_from_dump_files_matches_oracle(tmp_path):
     tc, tj = tt.lookup_host(probe)
     assert (oc == tc).all() and (oj == tj).all()
     assert tc[-1] == 12
+    def pk(t):
+        return np.array([int("".join({"A": "00", "C": "01", "G": "10", "T": "11"}[c] for c in t), 2)], dtype=np.uint64)
+    for text, want in (("GATTACAGATTACAGATTACA", 41), ("TTTTACAGATTACAGATTACA", 7), ("CCCCACAGATTACAGATTACA", 3),
+                       ("AAAAACAGATTACAGATTACA", 5)):
+        assert tt.lookup_host(pk(text))[0][0] == want == ot.lookup_packed(pk(text))[0][0], text
     # the oracle's map also holds the two unmatchable keys (N k-mer, short k-mer)
     assert len(ot) == len(tt) + 2
 
