@@ -97,7 +97,8 @@ int talc_device_count(void);
  * if junction_path is not NULL, colours k-mers from the junction dump (both strands,
  * jcount < coloured_count_thr, Jellyfish.cpp:273-290); then un-colours the 4 homopolymer
  * k-mers (utils.cpp:658-669).  Lines whose k-mer is not K letters of ACGT can never match a
- * query and are counted in stats but not stored.  stats (may be NULL) receives
+ * query and are counted in stats but not stored.  A count token that does not start with a number
+ * (std::stoi throws in the reference, Jellyfish.cpp:259) reads as 0 here.  stats (may be NULL) receives
  * {lines read, lines kept, malformed lines}. */
 int talc_table_build(const char* dump_path, const char* junction_path, const talc_params* p,
                      talc_table** out, int64_t stats[3]);
