@@ -1388,17 +1388,20 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
     flushed = done;
   };
 
+  // The load of a step's bucket is issued as soon as its address is known — right after the previous step has chosen
+  // its base, ahead of that step's aim / cycle checks and bookkeeping — so that the dependent memory latency runs
+  // under that work instead of after it.
+  uint64_t slot = table_slot(h, cap);
+  v8u32 b = *(const v8u32 TALC_AS4*)(tab + slot);
   while (done < maxSteps) {
-    // ---- the tip's bucket (linear probing from its home slot)
-    uint64_t slot = table_slot(h, cap);
-    v8u32 b;
+    // ---- the tip's bucket (linear probing from its home slot; the home slot's load is already in flight)
     bool found = false;
     while (true) {
-      b = *(const v8u32 TALC_AS4*)(tab + slot);
       const uint64_t bk = ((uint64_t)b[1] << 32) | b[0];
       if (bk == key) { found = true; break; }
       if (bk == kEmptyKey) break;
       if (++slot == cap) slot = 0;
+      b = *(const v8u32 TALC_AS4*)(tab + slot);
     }
     if (!found) break;
     // ---- exactly one successor with count >= MIN_COUNT?
@@ -1410,6 +1413,12 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
     uint64_t km2;
     if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
     else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
+    // ---- the next tip's bucket: issue its load now (the new tip's filter hash is the table hash of its successor
+    // key = the hash of this probe)
+    const uint64_t key2 = dirRight ? (km2 & m1) : (km2 >> 2);
+    const uint64_t h2 = table_hash(key2);
+    const uint64_t slot2 = table_slot(h2, cap);
+    const v8u32 b2 = *(const v8u32 TALC_AS4*)(tab + slot2);
     // ---- aim check (bridges): any hit is handled by the generic step
     if (nAims > 0) {
       bool hit = ballot64(myAim == km2) != 0ull;
@@ -1419,10 +1428,7 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
       }
       if (hit) break;
     }
-    // ---- cycle prefilter (query without inserting; a possible cycle goes to the generic step); the new tip's
-    // filter hash is the table hash of its successor key = the hash of the next probe
-    const uint64_t key2 = dirRight ? (km2 & m1) : (km2 >> 2);
-    const uint64_t h2 = table_hash(key2);
+    // ---- cycle prefilter (query without inserting; a possible cycle goes to the generic step)
     const int bwi = bloom_word(h2);
     const unsigned long long bm = bloom_mask(h2);
     const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
@@ -1433,7 +1439,7 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
     const int rs = done & 63;
     recN = lane_set(recN, (int)nc, rs);
     recB = lane_set(recB, which, rs);
-    kmer = km2; key = key2; h = h2;
+    kmer = km2; key = key2; h = h2; slot = slot2; b = b2;
     cnt = nc;
     ++len; ++done;
     if ((done & 63) == 0) flush();
