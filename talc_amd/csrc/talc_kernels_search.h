@@ -1331,7 +1331,8 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
 // to lane (step mod 64) of two registers, bases are stored and the distance terms
 // |c - n| / sqrt(c) evaluated 64 steps at a time, lane-parallel, then added in path order (the same
 // double operations in the same order as the step-by-step form).
-TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
+template <bool dirRight>
+TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
   const DevParams& P = X.P;
   const int l = lane_id();
   // (arguments of a non-inlined function arrive in vector registers: make every one of them scalar)
@@ -1341,7 +1342,6 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
   if (uni64(r0.nmask) != 0ull) return 0;
   const uint32_t K = (uint32_t)uni((int)P.K), MINC = (uint32_t)uni((int)P.MIN_COUNT), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
   const uint32_t seqCap = (uint32_t)uni((int)X.C.seqCap), PMAX = (uint32_t)uni((int)PATH_MAXLENGTH_);
-  const int dirRight = uni((int)X.dirRight);
   const uint64_t cap = uni64(X.T.capacity);
   const Bucket TALC_AS4* tab = (const Bucket TALC_AS4*)uni_ptr(dirRight ? X.T.right : X.T.left);
   const uint64_t kmask = (1ULL << (2 * K)) - 1, m1 = (1ULL << (2 * (K - 1))) - 1;
@@ -1409,16 +1409,16 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
     const int m = (int)(c0 >= MINC) | ((int)(c1 >= MINC) << 1) | ((int)(c2 >= MINC) << 2) | ((int)(c3 >= MINC) << 3);
     if (m == 0 || (m & (m - 1)) != 0) break;
     const int which = __builtin_ctz((unsigned)m);
-    const uint32_t nc = (which == 0) ? c0 : (which == 1) ? c1 : (which == 2) ? c2 : c3;
     uint64_t km2;
     if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
     else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
     // ---- the next tip's bucket: issue its load now (the new tip's filter hash is the table hash of its successor
-    // key = the hash of this probe)
+    // key = the hash of this probe); everything that does not feed the address comes after
     const uint64_t key2 = dirRight ? (km2 & m1) : (km2 >> 2);
     const uint64_t h2 = table_hash(key2);
     const uint64_t slot2 = table_slot(h2, cap);
     const v8u32 b2 = *(const v8u32 TALC_AS4*)(tab + slot2);
+    const uint32_t nc = max(max(c0, c1), max(c2, c3));   // the one count >= MIN_COUNT is the largest of the four
     // ---- aim check (bridges): any hit is handled by the generic step
     if (nAims > 0) {
       bool hit = ballot64(myAim == km2) != 0ull;
@@ -1460,6 +1460,11 @@ TALC_DN int fast_forward(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENG
   }
   LSYNC();
   return done;
+}
+
+TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
+  return uni((int)X.dirRight) ? fast_forward_dir<true>(len, stepCounter, PATH_MAXLENGTH, edge)
+                              : fast_forward_dir<false>(len, stepCounter, PATH_MAXLENGTH, edge);
 }
 
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
