@@ -147,11 +147,17 @@ TALC_D void wave_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, u
 // the same for one position per lane (K byte loads each)
 TALC_D void lane_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, uint64_t& nmask) {
   gcu8 g = (gcu8)s;
+  // all the byte loads are issued before the first one is used (K <= 31; the index is clamped, never out of the read)
+  uint32_t c[31];
+#pragma unroll
+  for (int j = 0; j < 31; ++j) c[j] = (uint32_t)g[j < K ? j : K - 1];
   uint64_t v = 0, nm = 0;
-  for (int j = 0; j < K; ++j) {
-    const uint32_t c = (uint32_t)g[j];
-    v = (v << 2) | (uint64_t)((c > 3u) ? 0u : c);
-    nm |= (uint64_t)(c > 3u) << j;
+#pragma unroll
+  for (int j = 0; j < 31; ++j) {
+    if (j < K) {
+      v = (v << 2) | (uint64_t)((c[j] > 3u) ? 0u : c[j]);
+      nm |= (uint64_t)(c[j] > 3u) << j;
+    }
   }
   kmer = v; nmask = nm;
 }
