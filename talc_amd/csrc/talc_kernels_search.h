@@ -1353,20 +1353,15 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
   const uint64_t kmask = (1ULL << (2 * K)) - 1, m1 = (1ULL << (2 * (K - 1))) - 1;
   uint64_t kmer = uni64(r0.kmer);
   uint32_t cnt = (uint32_t)uni((int)r0.cnt);
-  int len = uni(len_);
-  const int len0 = len;
+  const int len0 = uni(len_);
   const uint32_t sc0 = (uint32_t)uni((int)stepCounter_);
   // number of steps this call may commit: path length limit, buffer, and (edges) the next scoreEdges step
   int maxSteps = 0;
-  if (sc0 < PMAX && (uint32_t)len < seqCap) {
-    maxSteps = (int)min(PMAX - sc0, seqCap - (uint32_t)len);
+  if (sc0 < PMAX && (uint32_t)len0 < seqCap) {
+    maxSteps = (int)min(PMAX - sc0, seqCap - (uint32_t)len0);
     if (edge) maxSteps = min(maxSteps, (int)(CHECK - 1 - (sc0 % CHECK)));
   }
   gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
-  const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
-  const int nAims = edge ? 0 : uni(X.dirRight ? X.nAncR : X.nAncL);
-  uint64_t myAim = ~0ull;   // no k-mer has the top bits set
-  if (l < min(nAims, AIMS_LDS) && g_aimN[l] == 0ull) myAim = g_aimK[l];
   const unsigned long long bw0 = g_bloom[l];
   int bwLo = (int)(uint32_t)bw0, bwHi = (int)(uint32_t)(bw0 >> 32);
   int recN = 0, recB = 0;
@@ -1374,7 +1369,6 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
   double dist = r0.dist;
   int done = 0, flushed = 0;
   uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
-  uint64_t h = table_hash(key);
 
   auto flush = [&]() {
     const int n = done - flushed;
@@ -1397,7 +1391,7 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
   // The load of a step's bucket is issued as soon as its address is known — right after the previous step has chosen
   // its base, ahead of that step's aim / cycle checks and bookkeeping — so that the dependent memory latency runs
   // under that work instead of after it.
-  uint64_t slot = table_slot(h, cap);
+  uint64_t slot = table_slot(table_hash(key), cap);
   v8u32 b = *(const v8u32 TALC_AS4*)(tab + slot);
   while (done < maxSteps) {
     // ---- the tip's bucket (linear probing from its home slot; the home slot's load is already in flight)
@@ -1410,44 +1404,45 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
       b = *(const v8u32 TALC_AS4*)(tab + slot);
     }
     if (!found) break;
-    // ---- exactly one successor with count >= MIN_COUNT?
+    // (keeps all eight registers of the load occupied until it has landed: the compiler would otherwise put a
+    //  temporary into the unused colour words and wait for the load right after issuing it)
+    asm volatile("" :: "s"(b[6]), "s"(b[7]));
+    // ---- exactly one successor with count >= MIN_COUNT?  (bit i of m: count i >= MIN_COUNT; the compare's SCC is
+    // shifted in with s_addc: two scalar instructions per count)
     const uint32_t c0 = b[2], c1 = b[3], c2 = b[4], c3 = b[5];
-    const int m = (int)(c0 >= MINC) | ((int)(c1 >= MINC) << 1) | ((int)(c2 >= MINC) << 2) | ((int)(c3 >= MINC) << 3);
+    int m;
+    asm("s_cmp_ge_u32 %4, %5\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_ge_u32 %3, %5\n\ts_addc_u32 %0, %0, %0\n\t"
+        "s_cmp_ge_u32 %2, %5\n\ts_addc_u32 %0, %0, %0\n\ts_cmp_ge_u32 %1, %5\n\ts_addc_u32 %0, %0, %0"
+        : "=&s"(m) : "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(MINC) : "scc");
     if (m == 0 || (m & (m - 1)) != 0) break;
     const int which = __builtin_ctz((unsigned)m);
+    uint32_t nc;   // the one count >= MIN_COUNT is the largest of the four (taken before the next load reuses b's registers)
+    asm("s_max_u32 %0, %1, %2\n\ts_max_u32 %0, %0, %3\n\ts_max_u32 %0, %0, %4" : "=&s"(nc) : "s"(c0), "s"(c1), "s"(c2), "s"(c3) : "scc");
     uint64_t km2;
     if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
     else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
     // ---- the next tip's bucket: issue its load now (the new tip's filter hash is the table hash of its successor
     // key = the hash of this probe); everything that does not feed the address comes after
-    const uint64_t key2 = dirRight ? (km2 & m1) : (km2 >> 2);
-    const uint64_t h2 = table_hash(key2);
-    const uint64_t slot2 = table_slot(h2, cap);
-    const v8u32 b2 = *(const v8u32 TALC_AS4*)(tab + slot2);
-    const uint32_t nc = max(max(c0, c1), max(c2, c3));   // the one count >= MIN_COUNT is the largest of the four
-    // ---- aim check (bridges): any hit is handled by the generic step
-    if (nAims > 0) {
-      bool hit = ballot64(myAim == km2) != 0ull;
-      for (int ab = AIMS_LDS; ab < nAims && !hit; ab += 64) {
-        const int ai = ab + l;
-        hit = ballot64((ai < nAims) && (aims[ai].kmer == km2) && (aims[ai].nmask == 0ull)) != 0ull;
-      }
-      if (hit) break;
-    }
-    // ---- cycle prefilter (query without inserting; a possible cycle goes to the generic step)
+    key = dirRight ? (km2 & m1) : (km2 >> 2);
+    const uint64_t h2 = table_hash(key);
+    slot = table_slot(h2, cap);
+    b = *(const v8u32 TALC_AS4*)(tab + slot);
+    // ---- aim check (bridges) and cycle prefilter in one query: the search's filter holds the aims as well as every
+    // k-mer walked so far (init_first_trail), so "absent" means neither an aim nor a cycle; a possible hit of either
+    // kind is left to the generic step, which redoes this step from the unchanged state
     const int bwi = bloom_word(h2);
     const unsigned long long bm = bloom_mask(h2);
     const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
-    if (((bv & bm) == bm) && (len > (int)K)) break;
+    if ((bv & bm) == bm) break;
     // ---- commit the step
     bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
     bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
     const int rs = done & 63;
     recN = lane_set(recN, (int)nc, rs);
     recB = lane_set(recB, which, rs);
-    kmer = km2; key = key2; h = h2; slot = slot2; b = b2;
+    kmer = km2;
     cnt = nc;
-    ++len; ++done;
+    ++done;
     if ((done & 63) == 0) flush();
   }
   flush();
@@ -1474,13 +1469,26 @@ TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH
 }
 
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
-TALC_D void init_first_trail(const AnchorRec& a) {
+// A bridge's search also enters its aims (the target anchors, Explorer.cpp:920) in the search's filter: the
+// fast-forward loop then needs no aim comparison of its own (a step onto an aim is a filter hit).
+TALC_D void init_first_trail(const AnchorRec& a, bool withAims) {
   const int K = (int)X.P.K;
   pool_reset();
   const uint32_t b0 = (uint32_t)pool_alloc();
   wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
   g_bloom[lane_id()] = 0ull;
   LSYNC();
+  if (withAims) {
+    const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
+    const int nAims = X.dirRight ? X.nAncR : X.nAncL;
+    for (int ai = lane_id(); ai < nAims; ai += 64) {
+      const AnchorRec t = aims[ai];
+      if (t.nmask != 0ull) continue;   // a fast-forwarded tip never holds an N
+      const uint64_t h = bloom_hash(t.kmer, 0ull);
+      atomicOr(&g_bloom[bloom_word(h)], bloom_mask(h));
+    }
+    LSYNC();
+  }
   bloom_query_insert(a.kmer, a.nmask);
   if (lane_id() == 0) {
     TrailRec r;
@@ -1541,7 +1549,7 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
     }
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
-    PROF_BEGIN2(); init_first_trail(a); PROF_END2(PF_INITTR);
+    PROF_BEGIN2(); init_first_trail(a, true); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
@@ -1643,7 +1651,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     }
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
-    PROF_BEGIN2(); init_first_trail(a); PROF_END2(PF_INITTR);
+    PROF_BEGIN2(); init_first_trail(a, false); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
