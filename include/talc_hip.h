@@ -121,6 +121,10 @@ int talc_table_colour(talc_table* t, const uint64_t* jkmers, const int64_t* jcou
 int talc_table_decolour_repeats(talc_table* t);
 
 uint64_t talc_table_size(const talc_table* t);        /* SR_DBG.size() (main.cpp:237) */
+/* Device memory of one uploaded copy: the two bucket tables and the presence filter, plus the walk tables
+ * (2 * capacity * 64 bytes: the fast-forward's lookahead records) once an upload has built them.  An upload
+ * builds them when they leave at least half of the device's free memory to the correction batches;
+ * the environment variable TALC_WALK=0 turns them off, TALC_WALK=1 makes their allocation mandatory. */
 uint64_t talc_table_device_bytes(const talc_table* t);
 
 /* Copy the table to `device` (HBM resident, replicated per GPU).  The table becomes

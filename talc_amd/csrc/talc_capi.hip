@@ -257,7 +257,11 @@ int talc_table_decolour_repeats(talc_table* t) {
 }
 uint64_t talc_table_size(const talc_table* t) { return t ? t->h.nkmers : 0; }
 uint64_t talc_table_device_bytes(const talc_table* t) {
-  return t ? 2 * t->h.capacity * sizeof(Bucket) + std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64) * 8 : 0;
+  if (!t) return 0;
+  uint64_t b = 2 * t->h.capacity * sizeof(Bucket) + std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64) * 8;
+  for (const auto& kv : t->h.dev)   // walk tables, where an upload built them
+    if (kv.second.walkRight) { b += 2 * t->h.capacity * sizeof(WalkEntry); break; }
+  return b;
 }
 
 int talc_table_upload(talc_table* t, int device) {
@@ -277,6 +281,28 @@ int talc_table_upload(talc_table* t, int device) {
     HIPCHK(hipMalloc((void**)&dc.filter, f.size() * 8));
     HIPCHK(hipMemcpy(dc.filter, f.data(), f.size() * 8, hipMemcpyHostToDevice));
   }
+  // walk tables (WalkEntry, talc_common.h): twice the bucket tables' size again, so only when that leaves at least
+  // half of the device's free memory to the correction batches; TALC_WALK=0 turns them off, TALC_WALK=1 insists
+  {
+    const char* env = getenv("TALC_WALK");
+    const uint64_t wbytes = t->h.capacity * sizeof(WalkEntry);
+    size_t freeB = 0, totalB = 0;
+    HIPCHK(hipMemGetInfo(&freeB, &totalB));
+    const bool want = env ? atoi(env) != 0 : (2 * wbytes <= freeB / 2);
+    if (want && t->h.capacity) {
+      if (hipMalloc((void**)&dc.walkRight, wbytes) != hipSuccess || hipMalloc((void**)&dc.walkLeft, wbytes) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(dc.walkRight); dc.walkRight = dc.walkLeft = nullptr;
+        if (env) { hipFree(dc.right); hipFree(dc.left); hipFree(dc.filter); return fail(TALC_ERR_NOMEM, "TALC_WALK=1 but the walk tables (%llu bytes) do not fit the device", (unsigned long long)(2 * wbytes)); }
+      } else {
+        const uint64_t nthr = 2 * t->h.capacity;
+        hipLaunchKernelGGL(k_build_walk, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, 0, dc.right, dc.left, t->h.capacity,
+                           t->h.p.k, dc.walkRight, dc.walkLeft);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+      }
+    }
+  }
   t->h.dev[device] = dc;
   t->h.frozen = true;
   return TALC_OK;
@@ -287,6 +313,7 @@ static int table_view(talc_table* t, int device, TableView& v) {
   if (it == t->h.dev.end()) return fail(TALC_ERR_STATE, "table not uploaded to device %d", device);
   v.right = it->second.right; v.left = it->second.left; v.capacity = t->h.capacity; v.k = t->h.p.k;
   v.filter = it->second.filter; v.filterWords = it->second.filterWords;
+  v.walkRight = it->second.walkRight; v.walkLeft = it->second.walkLeft;
   return TALC_OK;
 }
 
@@ -339,7 +366,8 @@ int talc_table_lookup_host_batch(const talc_table* t, const uint64_t* kmers, uin
 void talc_table_destroy(talc_table* t) {
   if (!t) return;
   for (auto& kv : t->h.dev) {
-    if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.right); hipFree(kv.second.left); hipFree(kv.second.filter); }
+    if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.right); hipFree(kv.second.left); hipFree(kv.second.filter);
+      hipFree(kv.second.walkRight); hipFree(kv.second.walkLeft); }
   }
   delete t;
 }

@@ -31,6 +31,7 @@ typedef const uint8_t TALC_AS1* gcu8;
 typedef uint8_t TALC_AS1* gu8;
 typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
 typedef uint32_t v8u32 __attribute__((ext_vector_type(8)));
+typedef uint32_t v16u32 __attribute__((ext_vector_type(16)));
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // plain vector: usable through AS-qualified pointers
 #endif
 
@@ -52,6 +53,22 @@ static_assert(sizeof(Bucket) == 32, "bucket must be 32 bytes");
 
 static const uint64_t kEmptyKey = ~0ULL;
 
+// Walk table (device only, derived from a finished Bucket table, same capacity and slot order): what a Trail that
+// keeps following its only solid successor will meet over the next WALK_LEVELS steps, in one 64-byte record, so
+// that the single-Trail fast-forward pays one dependent memory access per WALK_LEVELS steps instead of per step.
+// Level 0 describes the bucket's own four counts, level j+1 the bucket reached from level j by appending level j's
+// largest-count base.  Per level: top = the largest count, and next = the largest of the other three (clamped to
+// 2^30-1) with the base of `top` in bits 30-31.  "Exactly one successor with count >= MIN_COUNT" (the only kind of
+// step the fast-forward takes) is top >= MIN_COUNT > next, that successor is the stored base and its count is top —
+// for any MIN_COUNT in [1, 2^30).  A level whose bucket does not exist is all zero (no step passes it).
+#define TALC_WALK_LEVELS 7
+struct __attribute__((aligned(64))) WalkEntry {
+  uint64_t key;                          // the bucket's key (kEmptyKey if unused)
+  uint32_t lvl[2 * TALC_WALK_LEVELS];    // {top, next | base << 30} per level
+};
+static_assert(sizeof(WalkEntry) == 64, "walk entry must be 64 bytes");
+static const uint32_t kWalkNextMask = 0x3FFFFFFFu;
+
 struct TableView {
   const Bucket* right;   // device (or host) pointer
   const Bucket* left;
@@ -62,6 +79,8 @@ struct TableView {
   // table (93 % of a noisy read's k-mers) without touching the table.  nullptr / 0 = no filter.
   const uint64_t* filter;
   uint64_t filterWords;
+  const WalkEntry* walkRight;   // walk tables of `right` / `left`; nullptr = not built (the fast-forward probes per step)
+  const WalkEntry* walkLeft;
 };
 
 TALC_HD uint64_t mix64(uint64_t x) {

@@ -1337,7 +1337,7 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
 // to lane (step mod 64) of two registers, bases are stored and the distance terms
 // |c - n| / sqrt(c) evaluated 64 steps at a time, lane-parallel, then added in path order (the same
 // double operations in the same order as the step-by-step form).
-template <bool dirRight>
+template <bool dirRight, bool WALK>
 TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
   const DevParams& P = X.P;
   const int l = lane_id();
@@ -1388,62 +1388,108 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
     flushed = done;
   };
 
-  // The load of a step's bucket is issued as soon as its address is known — right after the previous step has chosen
-  // its base, ahead of that step's aim / cycle checks and bookkeeping — so that the dependent memory latency runs
-  // under that work instead of after it.
-  uint64_t slot = table_slot(table_hash(key), cap);
-  v8u32 b = *(const v8u32 TALC_AS4*)(tab + slot);
-  while (done < maxSteps) {
-    // ---- the tip's bucket (linear probing from its home slot; the home slot's load is already in flight)
-    bool found = false;
-    while (true) {
-      const uint64_t bk = ((uint64_t)b[1] << 32) | b[0];
-      if (bk == key) { found = true; break; }
-      if (bk == kEmptyKey) break;
-      if (++slot == cap) slot = 0;
-      b = *(const v8u32 TALC_AS4*)(tab + slot);
+  if constexpr (WALK) {
+    // ---- walk-table form: one 64-byte record (talc_common.h) answers up to TALC_WALK_LEVELS consecutive steps, so
+    // the dependent memory access is paid once per record instead of once per step
+    const WalkEntry TALC_AS4* wtab = (const WalkEntry TALC_AS4*)uni_ptr(dirRight ? X.T.walkRight : X.T.walkLeft);
+    uint32_t hh = (uint32_t)(table_hash(key) >> 32);
+    while (done < maxSteps) {
+      if (done - flushed > 64 - TALC_WALK_LEVELS) flush();   // room for a whole record's steps in the 64 lanes
+      uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
+      v16u32 e = *(const v16u32 TALC_AS4*)(wtab + slot);
+      while (true) {   // linear probing, as in the bucket table (same slots)
+        const uint64_t bk = ((uint64_t)e[1] << 32) | e[0];
+        if (bk == key) break;
+        if (bk == kEmptyKey) goto walk_done;
+        if (++slot == cap) slot = 0;
+        e = *(const v16u32 TALC_AS4*)(wtab + slot);
+      }
+#pragma unroll
+      for (int j = 0; j < TALC_WALK_LEVELS; ++j) {
+        const uint32_t top = e[2 + 2 * j], nextw = e[3 + 2 * j];
+        // exactly one successor with count >= MIN_COUNT: the largest count reaches it, the next one does not
+        if (top < MINC || (nextw & kWalkNextMask) >= MINC) goto walk_done;
+        const int which = (int)(nextw >> 30);
+        uint64_t km2;
+        if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
+        else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
+        const uint64_t key2 = dirRight ? (km2 & m1) : (km2 >> 2);
+        const uint64_t h2 = table_hash(key2);
+        // aim / cycle query (see the per-step form below)
+        const int bwi = bloom_word(h2);
+        const unsigned long long bm = bloom_mask(h2);
+        const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
+        if ((bv & bm) == bm) goto walk_done;
+        bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
+        bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
+        const int rs = done - flushed;
+        recN = lane_set(recN, (int)top, rs);
+        recB = lane_set(recB, which, rs);
+        kmer = km2; key = key2; hh = (uint32_t)(h2 >> 32);
+        cnt = top;
+        ++done;
+        if (done >= maxSteps) goto walk_done;
+      }
     }
-    if (!found) break;
-    // (keeps all eight registers of the load occupied until it has landed: the compiler would otherwise put a
-    //  temporary into the unused colour words and wait for the load right after issuing it)
-    asm volatile("" :: "s"(b[6]), "s"(b[7]));
-    // ---- exactly one successor with count >= MIN_COUNT?  (bit i of m: count i >= MIN_COUNT; the compare's SCC is
-    // shifted in with s_addc: two scalar instructions per count)
-    const uint32_t c0 = b[2], c1 = b[3], c2 = b[4], c3 = b[5];
-    int m;
-    asm("s_cmp_ge_u32 %4, %5\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_ge_u32 %3, %5\n\ts_addc_u32 %0, %0, %0\n\t"
-        "s_cmp_ge_u32 %2, %5\n\ts_addc_u32 %0, %0, %0\n\ts_cmp_ge_u32 %1, %5\n\ts_addc_u32 %0, %0, %0"
-        : "=&s"(m) : "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(MINC) : "scc");
-    if (m == 0 || (m & (m - 1)) != 0) break;
-    const int which = __builtin_ctz((unsigned)m);
-    uint32_t nc;   // the one count >= MIN_COUNT is the largest of the four (taken before the next load reuses b's registers)
-    asm("s_max_u32 %0, %1, %2\n\ts_max_u32 %0, %0, %3\n\ts_max_u32 %0, %0, %4" : "=&s"(nc) : "s"(c0), "s"(c1), "s"(c2), "s"(c3) : "scc");
-    uint64_t km2;
-    if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
-    else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
-    // ---- the next tip's bucket: issue its load now (the new tip's filter hash is the table hash of its successor
-    // key = the hash of this probe); everything that does not feed the address comes after
-    key = dirRight ? (km2 & m1) : (km2 >> 2);
-    const uint64_t h2 = table_hash(key);
-    slot = table_slot(h2, cap);
-    b = *(const v8u32 TALC_AS4*)(tab + slot);
-    // ---- aim check (bridges) and cycle prefilter in one query: the search's filter holds the aims as well as every
-    // k-mer walked so far (init_first_trail), so "absent" means neither an aim nor a cycle; a possible hit of either
-    // kind is left to the generic step, which redoes this step from the unchanged state
-    const int bwi = bloom_word(h2);
-    const unsigned long long bm = bloom_mask(h2);
-    const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
-    if ((bv & bm) == bm) break;
-    // ---- commit the step
-    bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
-    bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
-    const int rs = done & 63;
-    recN = lane_set(recN, (int)nc, rs);
-    recB = lane_set(recB, which, rs);
-    kmer = km2;
-    cnt = nc;
-    ++done;
-    if ((done & 63) == 0) flush();
+  walk_done:;
+  } else {
+    // The load of a step's bucket is issued as soon as its address is known — right after the previous step has chosen
+    // its base, ahead of that step's aim / cycle checks and bookkeeping — so that the dependent memory latency runs
+    // under that work instead of after it.
+    uint64_t slot = table_slot(table_hash(key), cap);
+    v8u32 b = *(const v8u32 TALC_AS4*)(tab + slot);
+    while (done < maxSteps) {
+      // ---- the tip's bucket (linear probing from its home slot; the home slot's load is already in flight)
+      bool found = false;
+      while (true) {
+        const uint64_t bk = ((uint64_t)b[1] << 32) | b[0];
+        if (bk == key) { found = true; break; }
+        if (bk == kEmptyKey) break;
+        if (++slot == cap) slot = 0;
+        b = *(const v8u32 TALC_AS4*)(tab + slot);
+      }
+      if (!found) break;
+      // (keeps all eight registers of the load occupied until it has landed: the compiler would otherwise put a
+      //  temporary into the unused colour words and wait for the load right after issuing it)
+      asm volatile("" :: "s"(b[6]), "s"(b[7]));
+      // ---- exactly one successor with count >= MIN_COUNT?  (bit i of m: count i >= MIN_COUNT; the compare's SCC is
+      // shifted in with s_addc: two scalar instructions per count)
+      const uint32_t c0 = b[2], c1 = b[3], c2 = b[4], c3 = b[5];
+      int m;
+      asm("s_cmp_ge_u32 %4, %5\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_ge_u32 %3, %5\n\ts_addc_u32 %0, %0, %0\n\t"
+          "s_cmp_ge_u32 %2, %5\n\ts_addc_u32 %0, %0, %0\n\ts_cmp_ge_u32 %1, %5\n\ts_addc_u32 %0, %0, %0"
+          : "=&s"(m) : "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(MINC) : "scc");
+      if (m == 0 || (m & (m - 1)) != 0) break;
+      const int which = __builtin_ctz((unsigned)m);
+      uint32_t nc;   // the one count >= MIN_COUNT is the largest of the four (taken before the next load reuses b's registers)
+      asm("s_max_u32 %0, %1, %2\n\ts_max_u32 %0, %0, %3\n\ts_max_u32 %0, %0, %4" : "=&s"(nc) : "s"(c0), "s"(c1), "s"(c2), "s"(c3) : "scc");
+      uint64_t km2;
+      if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
+      else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
+      // ---- the next tip's bucket: issue its load now (the new tip's filter hash is the table hash of its successor
+      // key = the hash of this probe); everything that does not feed the address comes after
+      key = dirRight ? (km2 & m1) : (km2 >> 2);
+      const uint64_t h2 = table_hash(key);
+      slot = table_slot(h2, cap);
+      b = *(const v8u32 TALC_AS4*)(tab + slot);
+      // ---- aim check (bridges) and cycle prefilter in one query: the search's filter holds the aims as well as every
+      // k-mer walked so far (init_first_trail), so "absent" means neither an aim nor a cycle; a possible hit of either
+      // kind is left to the generic step, which redoes this step from the unchanged state
+      const int bwi = bloom_word(h2);
+      const unsigned long long bm = bloom_mask(h2);
+      const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
+      if ((bv & bm) == bm) break;
+      // ---- commit the step
+      bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
+      bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
+      const int rs = done - flushed;
+      recN = lane_set(recN, (int)nc, rs);
+      recB = lane_set(recB, which, rs);
+      kmer = km2;
+      cnt = nc;
+      ++done;
+      if (done - flushed == 64) flush();
+    }
   }
   flush();
   g_bloom[l] = ((unsigned long long)(uint32_t)bwHi << 32) | (uint32_t)bwLo;
@@ -1464,8 +1510,12 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
 }
 
 TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
-  return uni((int)X.dirRight) ? fast_forward_dir<true>(len, stepCounter, PATH_MAXLENGTH, edge)
-                              : fast_forward_dir<false>(len, stepCounter, PATH_MAXLENGTH, edge);
+  // the walk tables encode "count >= MIN_COUNT" for MIN_COUNT below 2^30 only (talc_common.h)
+  if (uni((int)(X.T.walkRight != nullptr && X.P.MIN_COUNT <= kWalkNextMask)) != 0)
+    return uni((int)X.dirRight) ? fast_forward_dir<true, true>(len, stepCounter, PATH_MAXLENGTH, edge)
+                                : fast_forward_dir<false, true>(len, stepCounter, PATH_MAXLENGTH, edge);
+  return uni((int)X.dirRight) ? fast_forward_dir<true, false>(len, stepCounter, PATH_MAXLENGTH, edge)
+                              : fast_forward_dir<false, false>(len, stepCounter, PATH_MAXLENGTH, edge);
 }
 
 // first Trail of a search: the start anchor (Trail.cpp:57-65)

@@ -24,6 +24,8 @@ struct DeviceCopy {
   Bucket* left = nullptr;
   uint64_t* filter = nullptr;
   uint64_t filterWords = 0;
+  WalkEntry* walkRight = nullptr;
+  WalkEntry* walkLeft = nullptr;
 };
 
 struct HostTable {

@@ -372,6 +372,59 @@ def test_mixed_lengths_config5_shape():
     assert max(lens) > 3000 and min(l for l in lens if l > 31) < 1500
 
 
+# ---------------------------------------------------------------- walk tables (fast-forward accelerator)
+def test_walk_tables_do_not_change_results(gpu_pair, monkeypatch):
+    """The walk tables (WalkEntry, talc_common.h) are a derived device structure: with them (default, gpu_pair) and
+    without them (TALC_WALK=0: the per-step probing form of the fast-forward) every record is the same."""
+    bases, offs = gpu_pair.reads(9000, 400)
+    ref_out, ref_off, ref_st = gpu_pair.ctx.correct(bases, offs)
+    monkeypatch.setenv("TALC_WALK", "0")
+    t2 = T.Table.from_arrays(gpu_pair.keys, gpu_pair.counts, gpu_pair.p)
+    t2.decolour_repeats()
+    t2.upload(0)
+    assert 0 < t2.device_bytes < gpu_pair.ttab.device_bytes    # no walk tables in this copy
+    ctx2 = T.Context(t2, gpu_pair.p, 0)
+    out, oo, st = ctx2.correct(bases, offs)
+    assert np.array_equal(out, ref_out) and np.array_equal(oo, ref_off) and np.array_equal(st, ref_st)
+    ctx2.close()
+    # and the per-step form against the oracle as well
+    o_out, o_off, o_st = gpu_pair.otab.correct_batch(bases, offs, nthreads=8)
+    assert PU.seqs_of(o_out, o_off) == PU.seqs_of(out, oo) and np.array_equal(np.asarray(o_st), st)
+
+
+@pytest.mark.parametrize("form", ["walk-clamped", "per-step"])
+def test_walk_tables_with_counts_beyond_30_bits(form):
+    """Counts scaled up to 31 bits: a walk level stores the runner-up count clamped to 2^30-1, which is exact for
+    MIN_COUNT < 2^30; above that the fast-forward must not use the walk tables at all."""
+    from talc_amd.synth import Synth
+    S = Synth(target_kmers=200_000, k=21, seed=23)
+    keys, counts = S.dump_arrays()
+    if form == "walk-clamped":     # everything in proportion, the largest count just below 2^31
+        scale = ((1 << 31) - 1) // int(counts.max())
+        big = (counts.astype(np.uint64) * scale).astype(np.uint32)
+        minc = 2 * scale
+        assert minc < (1 << 30) and int((big > (1 << 30)).sum()) > 100
+    else:                          # MIN_COUNT itself beyond 30 bits (2 units), the upper half of the counts saturated
+        scale = (1 << 29) + 3
+        big = np.minimum(counts.astype(np.uint64) * scale, (1 << 31) - 1).astype(np.uint32)
+        minc = 2 * scale
+        assert minc > (1 << 30)
+    p, q = PU.both_params(k=21, min_count=minc)
+    otab = O.OracleTable(q, O.OracleTable.FLAT)
+    otab.insert_packed(keys, big)
+    otab.decolour()
+    ttab = T.Table.from_arrays(keys, big, p)
+    ttab.decolour_repeats()
+    ttab.upload(0)
+    ctx = T.Context(ttab, p, 0)
+    bases, offs = S.reads(0, 150)
+    o_out, o_off, o_st = otab.correct_batch(bases, offs, nthreads=8)
+    g_out, g_off, g_st = ctx.correct(bases, offs)
+    assert PU.seqs_of(o_out, o_off) == PU.seqs_of(g_out, g_off) and np.array_equal(np.asarray(o_st), g_st)
+    assert ctx.timing().n_trail_steps > 0
+    ctx.close()
+
+
 # ---------------------------------------------------------------- device table builder (SURVEY §8f.1)
 def test_device_built_table_equals_host_built_table(tmp_path):
     """talc_table_from_arrays_device / talc_table_build_device against the host builder on the same dump: same size,
