@@ -1337,7 +1337,7 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
 // to lane (step mod 64) of two registers, bases are stored and the distance terms
 // |c - n| / sqrt(c) evaluated 64 steps at a time, lane-parallel, then added in path order (the same
 // double operations in the same order as the step-by-step form).
-template <bool dirRight, bool WALK>
+template <bool dirRight>
 TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
   const DevParams& P = X.P;
   const int l = lane_id();
@@ -1388,111 +1388,205 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
     flushed = done;
   };
 
-  if constexpr (WALK) {
-    // ---- walk-table form: one 64-byte record (talc_common.h) answers up to TALC_WALK_LEVELS consecutive steps, so
-    // the dependent memory access is paid once per record instead of once per step
-    const WalkEntry TALC_AS4* wtab = (const WalkEntry TALC_AS4*)uni_ptr(dirRight ? X.T.walkRight : X.T.walkLeft);
-    uint32_t hh = (uint32_t)(table_hash(key) >> 32);
-    while (done < maxSteps) {
-      if (done - flushed > 64 - TALC_WALK_LEVELS) flush();   // room for a whole record's steps in the 64 lanes
-      uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
-      v16u32 e = *(const v16u32 TALC_AS4*)(wtab + slot);
-      while (true) {   // linear probing, as in the bucket table (same slots)
-        const uint64_t bk = ((uint64_t)e[1] << 32) | e[0];
-        if (bk == key) break;
-        if (bk == kEmptyKey) goto walk_done;
-        if (++slot == cap) slot = 0;
-        e = *(const v16u32 TALC_AS4*)(wtab + slot);
-      }
-#pragma unroll
-      for (int j = 0; j < TALC_WALK_LEVELS; ++j) {
-        const uint32_t top = e[2 + 2 * j], nextw = e[3 + 2 * j];
-        // exactly one successor with count >= MIN_COUNT: the largest count reaches it, the next one does not
-        if (top < MINC || (nextw & kWalkNextMask) >= MINC) goto walk_done;
-        const int which = (int)(nextw >> 30);
-        uint64_t km2;
-        if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
-        else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
-        const uint64_t key2 = dirRight ? (km2 & m1) : (km2 >> 2);
-        const uint64_t h2 = table_hash(key2);
-        // aim / cycle query (see the per-step form below)
-        const int bwi = bloom_word(h2);
-        const unsigned long long bm = bloom_mask(h2);
-        const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
-        if ((bv & bm) == bm) goto walk_done;
-        bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
-        bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
-        const int rs = done - flushed;
-        recN = lane_set(recN, (int)top, rs);
-        recB = lane_set(recB, which, rs);
-        kmer = km2; key = key2; hh = (uint32_t)(h2 >> 32);
-        cnt = top;
-        ++done;
-        if (done >= maxSteps) goto walk_done;
-      }
-    }
-  walk_done:;
-  } else {
-    // The load of a step's bucket is issued as soon as its address is known — right after the previous step has chosen
-    // its base, ahead of that step's aim / cycle checks and bookkeeping — so that the dependent memory latency runs
-    // under that work instead of after it.
-    uint64_t slot = table_slot(table_hash(key), cap);
-    v8u32 b = *(const v8u32 TALC_AS4*)(tab + slot);
-    while (done < maxSteps) {
-      // ---- the tip's bucket (linear probing from its home slot; the home slot's load is already in flight)
-      bool found = false;
-      while (true) {
-        const uint64_t bk = ((uint64_t)b[1] << 32) | b[0];
-        if (bk == key) { found = true; break; }
-        if (bk == kEmptyKey) break;
-        if (++slot == cap) slot = 0;
-        b = *(const v8u32 TALC_AS4*)(tab + slot);
-      }
-      if (!found) break;
-      // (keeps all eight registers of the load occupied until it has landed: the compiler would otherwise put a
-      //  temporary into the unused colour words and wait for the load right after issuing it)
-      asm volatile("" :: "s"(b[6]), "s"(b[7]));
-      // ---- exactly one successor with count >= MIN_COUNT?  (bit i of m: count i >= MIN_COUNT; the compare's SCC is
-      // shifted in with s_addc: two scalar instructions per count)
-      const uint32_t c0 = b[2], c1 = b[3], c2 = b[4], c3 = b[5];
-      int m;
-      asm("s_cmp_ge_u32 %4, %5\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_ge_u32 %3, %5\n\ts_addc_u32 %0, %0, %0\n\t"
-          "s_cmp_ge_u32 %2, %5\n\ts_addc_u32 %0, %0, %0\n\ts_cmp_ge_u32 %1, %5\n\ts_addc_u32 %0, %0, %0"
-          : "=&s"(m) : "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(MINC) : "scc");
-      if (m == 0 || (m & (m - 1)) != 0) break;
-      const int which = __builtin_ctz((unsigned)m);
-      uint32_t nc;   // the one count >= MIN_COUNT is the largest of the four (taken before the next load reuses b's registers)
-      asm("s_max_u32 %0, %1, %2\n\ts_max_u32 %0, %0, %3\n\ts_max_u32 %0, %0, %4" : "=&s"(nc) : "s"(c0), "s"(c1), "s"(c2), "s"(c3) : "scc");
-      uint64_t km2;
-      if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
-      else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
-      // ---- the next tip's bucket: issue its load now (the new tip's filter hash is the table hash of its successor
-      // key = the hash of this probe); everything that does not feed the address comes after
-      key = dirRight ? (km2 & m1) : (km2 >> 2);
-      const uint64_t h2 = table_hash(key);
-      slot = table_slot(h2, cap);
+  // The load of a step's bucket is issued as soon as its address is known — right after the previous step has chosen
+  // its base, ahead of that step's aim / cycle checks and bookkeeping — so that the dependent memory latency runs
+  // under that work instead of after it.
+  uint64_t slot = table_slot(table_hash(key), cap);
+  v8u32 b = *(const v8u32 TALC_AS4*)(tab + slot);
+  while (done < maxSteps) {
+    // ---- the tip's bucket (linear probing from its home slot; the home slot's load is already in flight)
+    bool found = false;
+    while (true) {
+      const uint64_t bk = ((uint64_t)b[1] << 32) | b[0];
+      if (bk == key) { found = true; break; }
+      if (bk == kEmptyKey) break;
+      if (++slot == cap) slot = 0;
       b = *(const v8u32 TALC_AS4*)(tab + slot);
-      // ---- aim check (bridges) and cycle prefilter in one query: the search's filter holds the aims as well as every
-      // k-mer walked so far (init_first_trail), so "absent" means neither an aim nor a cycle; a possible hit of either
-      // kind is left to the generic step, which redoes this step from the unchanged state
-      const int bwi = bloom_word(h2);
-      const unsigned long long bm = bloom_mask(h2);
-      const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
-      if ((bv & bm) == bm) break;
-      // ---- commit the step
-      bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
-      bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
-      const int rs = done - flushed;
-      recN = lane_set(recN, (int)nc, rs);
-      recB = lane_set(recB, which, rs);
-      kmer = km2;
-      cnt = nc;
-      ++done;
-      if (done - flushed == 64) flush();
     }
+    if (!found) break;
+    // (keeps all eight registers of the load occupied until it has landed: the compiler would otherwise put a
+    //  temporary into the unused colour words and wait for the load right after issuing it)
+    asm volatile("" :: "s"(b[6]), "s"(b[7]));
+    // ---- exactly one successor with count >= MIN_COUNT?  (bit i of m: count i >= MIN_COUNT; the compare's SCC is
+    // shifted in with s_addc: two scalar instructions per count)
+    const uint32_t c0 = b[2], c1 = b[3], c2 = b[4], c3 = b[5];
+    int m;
+    asm("s_cmp_ge_u32 %4, %5\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_ge_u32 %3, %5\n\ts_addc_u32 %0, %0, %0\n\t"
+        "s_cmp_ge_u32 %2, %5\n\ts_addc_u32 %0, %0, %0\n\ts_cmp_ge_u32 %1, %5\n\ts_addc_u32 %0, %0, %0"
+        : "=&s"(m) : "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(MINC) : "scc");
+    if (m == 0 || (m & (m - 1)) != 0) break;
+    const int which = __builtin_ctz((unsigned)m);
+    uint32_t nc;   // the one count >= MIN_COUNT is the largest of the four (taken before the next load reuses b's registers)
+    asm("s_max_u32 %0, %1, %2\n\ts_max_u32 %0, %0, %3\n\ts_max_u32 %0, %0, %4" : "=&s"(nc) : "s"(c0), "s"(c1), "s"(c2), "s"(c3) : "scc");
+    uint64_t km2;
+    if (dirRight) km2 = ((kmer << 2) | (uint64_t)which) & kmask;
+    else km2 = ((uint64_t)which << (2 * (K - 1))) | (kmer >> 2);
+    // ---- the next tip's bucket: issue its load now (the new tip's filter hash is the table hash of its successor
+    // key = the hash of this probe); everything that does not feed the address comes after
+    key = dirRight ? (km2 & m1) : (km2 >> 2);
+    const uint64_t h2 = table_hash(key);
+    slot = table_slot(h2, cap);
+    b = *(const v8u32 TALC_AS4*)(tab + slot);
+    // ---- aim check (bridges) and cycle prefilter in one query: the search's filter holds the aims as well as every
+    // k-mer walked so far (init_first_trail), so "absent" means neither an aim nor a cycle; a possible hit of either
+    // kind is left to the generic step, which redoes this step from the unchanged state
+    const int bwi = bloom_word(h2);
+    const unsigned long long bm = bloom_mask(h2);
+    const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
+    if ((bv & bm) == bm) break;
+    // ---- commit the step
+    bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
+    bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
+    const int rs = done - flushed;
+    recN = lane_set(recN, (int)nc, rs);
+    recB = lane_set(recB, which, rs);
+    kmer = km2;
+    cnt = nc;
+    ++done;
+    if (done - flushed == 64) flush();
   }
+
   flush();
   g_bloom[l] = ((unsigned long long)(uint32_t)bwHi << 32) | (uint32_t)bwLo;
+  stepCounter_ = sc0 + (uint32_t)done;
+#ifdef TALC_PROF
+  if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (unsigned long long)done; }
+#endif
+  if (done) {
+    X.steps += (unsigned long long)done;
+    if (l == 0) {
+      TrailRec r = r0;
+      r.kmer = kmer; r.cnt = cnt; r.dist = dist;
+      tr_put(X.ia, 0, r);
+    }
+  }
+  LSYNC();
+  return done;
+}
+
+// ---- walk-table form of the fast-forward: one 64-byte record (WalkEntry, talc_common.h) describes the next
+// TALC_WALK_LEVELS steps of a Trail that keeps following its only solid successor, so a record's steps are taken
+// together, one level per lane: lane j < 7 loads level j (lane 7 the key), the lanes test "exactly one successor"
+// and build their k-mers from the prefix of the levels' bases, hash them, query the search's filter (LDS) — a
+// ballot gives the number of steps that can be committed, and those lanes insert their k-mers, store their bases
+// and record their counts.  One dependent memory access and ~100 instructions per record instead of per step.
+// A k-mer that repeats WITHIN a record (a cycle of period <= 6) would not be seen by a query that precedes the
+// record's inserts: lanes compare their hashes with the lower lanes' (equal hash = possible cycle = stop there).
+template <int P>
+TALC_D uint32_t dpp_row_shr(uint32_t v, uint32_t old) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x110 + P, 0xF, 0xF, false);
+}
+
+template <bool dirRight>
+TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
+  const DevParams& P = X.P;
+  const int l = lane_id();
+  const bool edge = uni((int)edge_) != 0;
+  if (uni((int)(X.tracing && X.trace.steps)) != 0) return 0;
+  const TrailRec r0 = tr_get(X.ia, 0);
+  if (uni64(r0.nmask) != 0ull) return 0;
+  const uint32_t K = (uint32_t)uni((int)P.K), MINC = (uint32_t)uni((int)P.MIN_COUNT), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
+  const uint32_t seqCap = (uint32_t)uni((int)X.C.seqCap), PMAX = (uint32_t)uni((int)PATH_MAXLENGTH_);
+  const uint64_t cap = uni64(X.T.capacity);
+  const uint32_t TALC_AS1* wtab = (const uint32_t TALC_AS1*)uni_ptr(dirRight ? X.T.walkRight : X.T.walkLeft);
+  const uint64_t kmask = (1ULL << (2 * K)) - 1, m1 = (1ULL << (2 * (K - 1))) - 1;
+  uint64_t kmer = uni64(r0.kmer);
+  uint32_t cnt = (uint32_t)uni((int)r0.cnt);
+  const int len0 = uni(len_);
+  const uint32_t sc0 = (uint32_t)uni((int)stepCounter_);
+  int maxSteps = 0;
+  if (sc0 < PMAX && (uint32_t)len0 < seqCap) {
+    maxSteps = (int)min(PMAX - sc0, seqCap - (uint32_t)len0);
+    if (edge) maxSteps = min(maxSteps, (int)(CHECK - 1 - (sc0 % CHECK)));
+  }
+  gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
+  uint32_t* recN = (uint32_t*)g_dp;   // counts of the committed, not yet flushed steps (the DP stage is idle here)
+  uint32_t cFlush = cnt;
+  double dist = r0.dist;
+  int done = 0, flushed = 0;
+
+  auto flush = [&]() {
+    const int n = done - flushed;
+    if (n <= 0) return;
+    // distance terms |c - n| / sqrt(c) (Explorer.cpp:1247): c of step j is n of step j-1
+    const uint32_t cn = (l < n) ? recN[l] : 1u;
+    const uint32_t cprev = (l == 0) ? cFlush : ((l < n) ? recN[l - 1] : 1u);
+    const double term = fabs((double)cprev - (double)cn) / sqrt((double)cprev);
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(term);
+    const int tLo = (int)(uint32_t)tb, tHi = (int)(uint32_t)(tb >> 32);
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long v = ((unsigned long long)(uint32_t)lane_get(tHi, j) << 32) | (uint32_t)lane_get(tLo, j);
+      dist = dist + __longlong_as_double((long long)v);
+    }
+    cFlush = (uint32_t)lane_get((int)cn, n - 1);
+    flushed = done;
+    LSYNC();
+  };
+
+  const int lv = min(l, TALC_WALK_LEVELS);                    // lanes >= 7 all read the key
+  const uint32_t laneOff = (lv < TALC_WALK_LEVELS) ? (uint32_t)(2 + 2 * lv) : 0u;
+  const int lj = min(l, TALC_WALK_LEVELS - 1);                // shift amounts stay in range on the idle lanes
+  uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
+  uint32_t hh = (uint32_t)(table_hash(key) >> 32);
+  while (done < maxSteps) {
+    if (done - flushed > 64 - TALC_WALK_LEVELS) flush();
+    uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
+    v2u32 e = *(const v2u32 TALC_AS1*)(wtab + slot * 16 + laneOff);
+    bool found = true;
+    while (true) {   // linear probing, as in the bucket table (same slots)
+      const uint64_t bk = ((uint64_t)(uint32_t)lane_get((int)e.y, TALC_WALK_LEVELS) << 32) | (uint32_t)lane_get((int)e.x, TALC_WALK_LEVELS);
+      if (bk == key) break;
+      if (bk == kEmptyKey) { found = false; break; }
+      if (++slot == cap) slot = 0;
+      e = *(const v2u32 TALC_AS1*)(wtab + slot * 16 + laneOff);
+    }
+    if (!found) break;
+    const uint32_t top = e.x, nextw = e.y;
+    // levels that are "exactly one successor with count >= MIN_COUNT", from level 0 up to the first that is not
+    const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && top >= MINC && (nextw & kWalkNextMask) < MINC);
+    int nOK = min(__builtin_ctzll(~passMask), maxSteps - done);
+    if (nOK == 0) break;
+    // lane j's tip after its step: the current tip shifted by j+1 bases, with the bases of levels 0..j
+    const uint32_t which = (l < TALC_WALK_LEVELS) ? (nextw >> 30) : 0u;
+    uint32_t pre = which << (dirRight ? 2 * (TALC_WALK_LEVELS - 1 - lj) : 2 * lj);
+    pre |= dpp_row_shr<1>(pre, 0u);
+    pre |= dpp_row_shr<2>(pre, 0u);
+    pre |= dpp_row_shr<4>(pre, 0u);
+    uint64_t km;
+    if (dirRight) km = ((kmer << (2 * (lj + 1))) | (uint64_t)(pre >> (2 * (TALC_WALK_LEVELS - 1 - lj)))) & kmask;
+    else km = ((uint64_t)pre << (2 * (K - 1 - (uint32_t)lj))) | (kmer >> (2 * (lj + 1)));
+    const uint64_t key2 = dirRight ? (km & m1) : (km >> 2);
+    const uint32_t hv = (uint32_t)(table_hash(key2) >> 32);   // the filter hash of the new tip = the hash of its probe
+    // possible cycle inside the record: the same hash on a lower lane
+    bool dup = dpp_row_shr<1>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<2>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<3>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<4>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<5>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<6>(hv, ~hv) == hv;
+    // aim / cycle query against the search's filter (init_first_trail entered the aims)
+    const int bwi = (int)(hv >> 26);
+    const unsigned long long bm = (1ull << ((hv >> 20) & 63u)) | (1ull << ((hv >> 14) & 63u));
+    const unsigned long long bv = g_bloom[bwi];
+    const unsigned long long hitMask = ballot64(((bv & bm) == bm) || dup) | (1ull << TALC_WALK_LEVELS);
+    nOK = min(nOK, __builtin_ctzll(hitMask));
+    if (nOK == 0) break;
+    // ---- commit nOK steps
+    if (l < nOK) {
+      atomicOr(&g_bloom[bwi], bm);
+      recN[done - flushed + l] = top;
+      seq[len0 + done + l] = (uint8_t)which;
+    }
+    const int last = nOK - 1;
+    kmer = ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(km >> 32), last) << 32) | (uint32_t)lane_get((int)(uint32_t)km, last);
+    key = dirRight ? (kmer & m1) : (kmer >> 2);
+    hh = (uint32_t)lane_get((int)hv, last);
+    cnt = (uint32_t)lane_get((int)top, last);
+    done += nOK;
+    LSYNC();
+    if (nOK < TALC_WALK_LEVELS) break;
+  }
+  flush();
   stepCounter_ = sc0 + (uint32_t)done;
 #ifdef TALC_PROF
   if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (unsigned long long)done; }
@@ -1512,10 +1606,10 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
 TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
   // the walk tables encode "count >= MIN_COUNT" for MIN_COUNT below 2^30 only (talc_common.h)
   if (uni((int)(X.T.walkRight != nullptr && X.P.MIN_COUNT <= kWalkNextMask)) != 0)
-    return uni((int)X.dirRight) ? fast_forward_dir<true, true>(len, stepCounter, PATH_MAXLENGTH, edge)
-                                : fast_forward_dir<false, true>(len, stepCounter, PATH_MAXLENGTH, edge);
-  return uni((int)X.dirRight) ? fast_forward_dir<true, false>(len, stepCounter, PATH_MAXLENGTH, edge)
-                              : fast_forward_dir<false, false>(len, stepCounter, PATH_MAXLENGTH, edge);
+    return uni((int)X.dirRight) ? fast_forward_walk<true>(len, stepCounter, PATH_MAXLENGTH, edge)
+                                : fast_forward_walk<false>(len, stepCounter, PATH_MAXLENGTH, edge);
+  return uni((int)X.dirRight) ? fast_forward_dir<true>(len, stepCounter, PATH_MAXLENGTH, edge)
+                              : fast_forward_dir<false>(len, stepCounter, PATH_MAXLENGTH, edge);
 }
 
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
