@@ -539,13 +539,18 @@ TALC_DN int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int mat
 
 // edit score (globalAlignment 0/-1/-1) and LCS length (localAlignment 1/0/0) of the same pair
 #define NW2_REG_NB 8
-TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, int& editScore, int& lcsLen) {
+// needEdit = false: only the LCS is wanted (the caller does not use the edit score: a single bridge candidate is not
+// compared with anything, Trajectory.cpp:282-303; an edge whose extension stopped takes the extension's own score,
+// Trail.cpp:408-434) — editScore is then left at 0.
+TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, int& editScore, int& lcsLen, bool needEdit_) {
   la = uni(la); lb = uni(lb);
+  const bool needEdit = uni((int)needEdit_) != 0;
   const uint8_t* a = uni_ptr(a_); const uint8_t* b = uni_ptr(b_);
   if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
   // both measures as wavefronts over the two sequences staged in LDS: the levels needed are the edit distance, and
   // (without the substitution move) la + lb - 2 LCS
-  bool haveEdit = false, haveLcs = false;
+  bool haveEdit = !needEdit, haveLcs = false;
+  if (!needEdit) editScore = 0;
   constexpr int STAGE = 3 * LDS_DP_CAP * 4;
   const int qpad = (la + 16) & ~7;
   if (lb > 0 && qpad + lb + 16 <= STAGE) {
@@ -557,20 +562,26 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
     if (l == 0) { stage[la] = 0xF0; stage[qpad + lb] = 0xF1; }
     WSYNC();
     unsigned long long ncells = 0;
-    int ed = -1;
-    const int lo = la - lb;   // the distance is at least the length difference
-    if (lo <= 31 && la <= 220) ed = wave_wfa_global<1, true>(stage, qpad, la, lb, ncells);
-    if (ed < 0 && lo <= 63 && la <= 440) ed = wave_wfa_global<2, true>(stage, qpad, la, lb, ncells);
-    if (ed < 0 && lo <= 127) ed = wave_wfa_global<4, true>(stage, qpad, la, lb, ncells);
-    if (ed >= 0) {
-      editScore = -ed; haveEdit = true;
-      const int hi = 2 * ed;   // each substitution is at most one insertion plus one deletion
-      int d = -1;
-      if (hi <= 31) d = wave_wfa_global<1, false>(stage, qpad, la, lb, ncells);
-      else if (hi <= 63) d = wave_wfa_global<2, false>(stage, qpad, la, lb, ncells);
-      else if (hi <= 127) d = wave_wfa_global<4, false>(stage, qpad, la, lb, ncells);
-      if (d >= 0) { lcsLen = (la + lb - d) >> 1; haveLcs = true; }
+    const int lo = la - lb;   // either distance is at least the length difference
+    int d = -1;
+    if (needEdit) {
+      int ed = -1;
+      if (lo <= 31 && la <= 220) ed = wave_wfa_global<1, true>(stage, qpad, la, lb, ncells);
+      if (ed < 0 && lo <= 63 && la <= 440) ed = wave_wfa_global<2, true>(stage, qpad, la, lb, ncells);
+      if (ed < 0 && lo <= 127) ed = wave_wfa_global<4, true>(stage, qpad, la, lb, ncells);
+      if (ed >= 0) {
+        editScore = -ed; haveEdit = true;
+        const int hi = 2 * ed;   // each substitution is at most one insertion plus one deletion
+        if (hi <= 31) d = wave_wfa_global<1, false>(stage, qpad, la, lb, ncells);
+        else if (hi <= 63) d = wave_wfa_global<2, false>(stage, qpad, la, lb, ncells);
+        else if (hi <= 127) d = wave_wfa_global<4, false>(stage, qpad, la, lb, ncells);
+      }
+    } else {   // no bound from the edit distance: narrowest wavefront first (-1 = it needs more levels than that width holds)
+      if (lo <= 31 && la <= 220) d = wave_wfa_global<1, false>(stage, qpad, la, lb, ncells);
+      if (d < 0 && lo <= 63 && la <= 440) d = wave_wfa_global<2, false>(stage, qpad, la, lb, ncells);
+      if (d < 0 && lo <= 127) d = wave_wfa_global<4, false>(stage, qpad, la, lb, ncells);
     }
+    if (d >= 0) { lcsLen = (la + lb - d) >> 1; haveLcs = true; }
     X.cells += ncells;
     WSYNC();
   }
@@ -928,7 +939,7 @@ TALC_DN void record_edge(int set, int t, int len0) {
     // score of the retained extension (Trail.cpp:408-434) and computePercentID (Trajectory.cpp:505-528):
     // -edit distance and LCS / max length of the same two extensions
     int es, lcs;
-    edit_and_lcs(A, cur.lenRefExt, Bq, cur.lenHistExt, es, lcs);
+    edit_and_lcs(A, cur.lenRefExt, Bq, cur.lenHistExt, es, lcs, !cur.stop);
     score = cur.stop ? (double)cur.score : (double)es;
     const double lenMax = (double)max(cur.lenRefExt, cur.lenHistExt);
     idscore = (double)lcs / lenMax;
@@ -1718,7 +1729,7 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
         double score, idv;
         // computeEditDistance / computeIDScore (Trajectory.cpp:386-428, 337-384): both non-empty here
         int es, lcs;
-        edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs);
+        edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs, X.nFull > 1);   // one candidate: its score is never compared
         score = (double)es;
         idv = (double)lcs / (double)max(X.refLen, fm.len);
         // cutAnchors INNER (Trajectory.cpp:176-197)
@@ -2066,7 +2077,7 @@ __global__ void k_pack(const uint8_t* __restrict__ outAll, const uint64_t* __res
 // mode 1: seed_and_extension(ref=a, cand=b, xdrop, dirRight, true) -> out[0..4] = lenRefExt, lenHistExt,
 //         posOnRef, score, stop
 // mode 2: wave_find_window(a, pattern=b, wantLast=p3)              -> out[0]
-// mode 4: edit_and_lcs(a, b)                                        -> out[0] = edit score, out[1] = LCS
+// mode 4: edit_and_lcs(a, b, needEdit = !p0)                        -> out[0] = edit score (0 if not asked), out[1] = LCS
 __global__ void __launch_bounds__(64)
 k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, int p1, int p2, int p3, int K,
           int* dpG, uint32_t dpCap, int* out, double alpha, double err, int minc) {
@@ -2087,7 +2098,7 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
   } else if (mode == 4) {
     // mode 4: edit_and_lcs(a, b) -> out[0] = global (0,-1,-1) score, out[1] = LCS length
     int es = 0, lcs = 0;
-    edit_and_lcs(a, la, b, lb, es, lcs);
+    edit_and_lcs(a, la, b, lb, es, lcs, p0 == 0);
     if (lane_id() == 0) { out[0] = es; out[1] = lcs; out[5] = (int)X.overflow; }
   } else {
     // mode 3: tag_next_nodes on the device.  a = 4 counts + 4 colours + count as 9 little-endian u32 (36 bytes),

@@ -144,6 +144,8 @@ def test_device_edit_distance_and_lcs_match_oracle(gpu_pair):
         exp_l = L.orc_global_alignment(a.encode(), b.encode(), 1, 0, 0, 0, 0, 0, 0)
         got = ctx.test_dp(4, a, b)
         assert got[5] == 0 and (got[0], got[1]) == (exp_e, exp_l), (len(a), len(b), got[:2].tolist(), exp_e, exp_l)
+        got = ctx.test_dp(4, a, b, p0=1)     # LCS only (the form used when the edit score is not needed)
+        assert got[5] == 0 and (got[0], got[1]) == (0, exp_l), (len(a), len(b), got[:2].tolist(), exp_l)
 
 
 def test_device_seed_and_extension_matches_oracle(gpu_pair):
