@@ -1217,10 +1217,11 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
 
 // Explorer::scoreEdges (Explorer.cpp:709-740) on the new set (n trails of length len); survivors
 // are compacted in place; returns their number
-TALC_DN int score_edges(int n, int len, int& xdrop) {
+// (ib = the Trail set to score: the new set of a generic step, or the current set when the fast-forward took the step)
+TALC_DN int score_edges(int ib_, int n, int len, int& xdrop) {
   if (n == 0) return 0;
   const int l = lane_id();
-  const int ib = X.ia ^ 1;
+  const int ib = uni(ib_);
   xdrop += 2;
   int new_xdrop = 0;
   int nSel = 0;
@@ -1318,7 +1319,7 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
   ++stepCounter;
   int nOut;
   if ((stepCounter % P.CHECK_INTERVAL == 0) || ((uint32_t)nNew >= P.MAX_BORDER_PATHS)) {
-    nNew = score_edges(nNew, len + 1, xdrop);
+    nNew = score_edges(X.ia ^ 1, nNew, len + 1, xdrop);
     if (nNew > 5) {
       bool cx = false;
       PROF_BEGIN();
@@ -1370,7 +1371,7 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
   int maxSteps = 0;
   if (sc0 < PMAX && (uint32_t)len0 < seqCap) {
     maxSteps = (int)min(PMAX - sc0, seqCap - (uint32_t)len0);
-    if (edge) maxSteps = min(maxSteps, (int)(CHECK - 1 - (sc0 % CHECK)));
+    if (edge) maxSteps = min(maxSteps, (int)(CHECK - (sc0 % CHECK)));   // up to and including the next scoring step
   }
   gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
   const unsigned long long bw0 = g_bloom[l];
@@ -1508,7 +1509,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   int maxSteps = 0;
   if (sc0 < PMAX && (uint32_t)len0 < seqCap) {
     maxSteps = (int)min(PMAX - sc0, seqCap - (uint32_t)len0);
-    if (edge) maxSteps = min(maxSteps, (int)(CHECK - 1 - (sc0 % CHECK)));
+    if (edge) maxSteps = min(maxSteps, (int)(CHECK - (sc0 % CHECK)));   // up to and including the next scoring step
   }
   gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
   uint32_t* recN = (uint32_t*)g_dp;   // counts of the committed, not yet flushed steps (the DP stage is idle here)
@@ -1810,7 +1811,21 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
-      if (nCur == 1) { PROF_BEGIN2(); len += fast_forward(len, stepCounter, PATH_MAXLENGTH, true); PROF_END2(PF_FFWD); if (!(stepCounter < PATH_MAXLENGTH)) break; }
+      if (nCur == 1) {
+        PROF_BEGIN2();
+        const int ff = fast_forward(len, stepCounter, PATH_MAXLENGTH, true);
+        len += ff;
+        PROF_END2(PF_FFWD);
+        if (ff > 0 && (stepCounter % P.CHECK_INTERVAL == 0)) {
+          // the fast-forward took the step after which scoring is due (Explorer.cpp:672-686): the one Trail stays
+          // where it is (set ia, slot 0) — score it there; five or fewer survivors means no gardening
+          PROF_BEGIN2();
+          nCur = score_edges(X.ia, 1, len, xdrop);
+          PROF_END2(PF_STEPE);
+          continue;
+        }
+        if (!(stepCounter < PATH_MAXLENGTH)) break;
+      }
       PROF_BEGIN2();
       nCur = step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop);
       PROF_END2(PF_STEPE);
