@@ -57,17 +57,20 @@ static const uint64_t kEmptyKey = ~0ULL;
 // keeps following its only solid successor will meet over the next WALK_LEVELS steps, in one 64-byte record, so
 // that the single-Trail fast-forward pays one dependent memory access per WALK_LEVELS steps instead of per step.
 // Level 0 describes the bucket's own four counts, level j+1 the bucket reached from level j by appending level j's
-// largest-count base.  Per level: top = the largest count, and next = the largest of the other three (clamped to
-// 2^30-1) with the base of `top` in bits 30-31.  "Exactly one successor with count >= MIN_COUNT" (the only kind of
-// step the fast-forward takes) is top >= MIN_COUNT > next, that successor is the stored base and its count is top —
-// for any MIN_COUNT in [1, 2^30).  A level whose bucket does not exist is all zero (no step passes it).
-#define TALC_WALK_LEVELS 7
+// largest-count base.  One 32-bit word per level: bits 0-15 top = the largest count (0xFFFF: does not fit, the walk
+// stops at this level), bits 16-29 next = the largest of the other three clamped to 2^14-1, bits 30-31 the base of
+// `top`.  "Exactly one successor with count >= MIN_COUNT" (the only kind of step the fast-forward takes) is
+// top >= MIN_COUNT > next, that successor is the stored base and its count is top — exact for any MIN_COUNT in
+// [1, 2^14); a level whose bucket does not exist is all zero (no step passes it).  Whatever a record cannot express
+// (a count beyond 16 bits, MIN_COUNT beyond 14) is left to the per-step form / the generic step: never wrong, only slower.
+#define TALC_WALK_LEVELS 14
 struct __attribute__((aligned(64))) WalkEntry {
-  uint64_t key;                          // the bucket's key (kEmptyKey if unused)
-  uint32_t lvl[2 * TALC_WALK_LEVELS];    // {top, next | base << 30} per level
+  uint64_t key;                      // the bucket's key (kEmptyKey if unused)
+  uint32_t lvl[TALC_WALK_LEVELS];    // top | next << 16 | base << 30 per level
 };
 static_assert(sizeof(WalkEntry) == 64, "walk entry must be 64 bytes");
-static const uint32_t kWalkNextMask = 0x3FFFFFFFu;
+static const uint32_t kWalkTopNone = 0xFFFFu;
+static const uint32_t kWalkNextMask = 0x3FFFu;
 
 struct TableView {
   const Bucket* right;   // device (or host) pointer

@@ -101,15 +101,15 @@ __global__ void k_build_finalize(Bucket* right, Bucket* left, uint64_t cap, unsi
 // ------------------------------------------------------------------ walk tables (WalkEntry, talc_common.h)
 // One thread per bucket of either table: level 0 from the bucket's own counts, then up to WALK_LEVELS-1 dependent
 // probes along the largest-count successor.  Runs once per upload.
-TALC_D void walk_level(const uint32_t c[4], uint32_t& top, uint32_t& nextw) {
-  int am = 0;
+TALC_D uint32_t walk_level(const uint32_t c[4], uint32_t& top) {
+  uint32_t am = 0;
   top = c[0];
 #pragma unroll
-  for (int b = 1; b < 4; ++b) if (c[b] > top) { top = c[b]; am = b; }
+  for (uint32_t b = 1; b < 4; ++b) if (c[b] > top) { top = c[b]; am = b; }
   uint32_t nx = 0;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) if (b != am && c[b] > nx) nx = c[b];
-  nextw = (nx < kWalkNextMask ? nx : kWalkNextMask) | ((uint32_t)am << 30);
+  for (uint32_t b = 0; b < 4; ++b) if (b != am && c[b] > nx) nx = c[b];
+  return (top < kWalkTopNone ? top : kWalkTopNone) | ((nx < kWalkNextMask ? nx : kWalkNextMask) << 16) | (am << 30);
 }
 
 __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __restrict__ left, uint64_t cap, uint32_t K,
@@ -122,26 +122,25 @@ __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __r
   const uint64_t m1 = (1ULL << (2 * (K - 1))) - 1;
   BucketRegs r = load_bucket(tab + s);
   const uint64_t key0 = r.key;
-  uint32_t lv[2 * TALC_WALK_LEVELS];
+  uint32_t lv[TALC_WALK_LEVELS];
 #pragma unroll
-  for (int i = 0; i < 2 * TALC_WALK_LEVELS; ++i) lv[i] = 0;
+  for (int i = 0; i < TALC_WALK_LEVELS; ++i) lv[i] = 0;
   if (key0 != kEmptyKey) {
     uint64_t key = key0;
 #pragma unroll
     for (int lev = 0; lev < TALC_WALK_LEVELS; ++lev) {
-      uint32_t top, nextw;
-      walk_level(r.cnt, top, nextw);
-      lv[2 * lev] = top; lv[2 * lev + 1] = nextw;
-      if (top == 0 || lev == TALC_WALK_LEVELS - 1) break;
-      const uint64_t am = nextw >> 30;
+      uint32_t top;
+      const uint32_t w = walk_level(r.cnt, top);
+      lv[lev] = w;
+      if (top == 0 || top >= kWalkTopNone || lev == TALC_WALK_LEVELS - 1) break;   // nothing usable beyond this level
+      const uint64_t am = w >> 30;
       // successor key: RIGHT appends the base to the (K-1)-mer and drops its first base, LEFT prepends and drops the last
       key = dirRight ? (((key << 2) | am) & m1) : ((am << (2 * (K - 2))) | (key >> 2));
       if (!probe_bucket(tab, cap, key, r)) break;   // no such bucket: the remaining levels stay zero
     }
   }
   v4u32 TALC_AS1* out = (v4u32 TALC_AS1*)((dirRight ? walkRight : walkLeft) + s);
-  v4u32 w0; w0.x = (uint32_t)key0; w0.y = (uint32_t)(key0 >> 32); w0.z = lv[0]; w0.w = lv[1];
-  out[0] = w0;
+  out[0] = v4u32{(uint32_t)key0, (uint32_t)(key0 >> 32), lv[0], lv[1]};
   out[1] = v4u32{lv[2], lv[3], lv[4], lv[5]};
   out[2] = v4u32{lv[6], lv[7], lv[8], lv[9]};
   out[3] = v4u32{lv[10], lv[11], lv[12], lv[13]};

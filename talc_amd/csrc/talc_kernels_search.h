@@ -1478,11 +1478,11 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
 
 // ---- walk-table form of the fast-forward: one 64-byte record (WalkEntry, talc_common.h) describes the next
 // TALC_WALK_LEVELS steps of a Trail that keeps following its only solid successor, so a record's steps are taken
-// together, one level per lane: lane j < 7 loads level j (lane 7 the key), the lanes test "exactly one successor"
+// together, one level per lane: lane j < 14 loads level j (lanes 14, 15 the key), the lanes test "exactly one successor"
 // and build their k-mers from the prefix of the levels' bases, hash them, query the search's filter (LDS) — a
 // ballot gives the number of steps that can be committed, and those lanes insert their k-mers, store their bases
-// and record their counts.  One dependent memory access and ~100 instructions per record instead of per step.
-// A k-mer that repeats WITHIN a record (a cycle of period <= 6) would not be seen by a query that precedes the
+// and record their counts.  One dependent memory access and ~130 instructions per record instead of per step.
+// A k-mer that repeats WITHIN a record (a cycle of period <= 13) would not be seen by a query that precedes the
 // record's inserts: lanes compare their hashes with the lower lanes' (equal hash = possible cycle = stop there).
 template <int P>
 TALC_D uint32_t dpp_row_shr(uint32_t v, uint32_t old) {
@@ -1535,35 +1535,36 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     LSYNC();
   };
 
-  const int lv = min(l, TALC_WALK_LEVELS);                    // lanes >= 7 all read the key
-  const uint32_t laneOff = (lv < TALC_WALK_LEVELS) ? (uint32_t)(2 + 2 * lv) : 0u;
+  // lane j < 14 reads level j, lanes 14 / 15 the two halves of the key (the lanes above them repeat lane 14)
+  const uint32_t laneOff = (l < TALC_WALK_LEVELS) ? (uint32_t)(2 + l) : (l == TALC_WALK_LEVELS + 1 ? 1u : 0u);
   const int lj = min(l, TALC_WALK_LEVELS - 1);                // shift amounts stay in range on the idle lanes
   uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
   uint32_t hh = (uint32_t)(table_hash(key) >> 32);
   while (done < maxSteps) {
     if (done - flushed > 64 - TALC_WALK_LEVELS) flush();
     uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
-    v2u32 e = *(const v2u32 TALC_AS1*)(wtab + slot * 16 + laneOff);
+    uint32_t e = wtab[slot * 16 + laneOff];
     bool found = true;
     while (true) {   // linear probing, as in the bucket table (same slots)
-      const uint64_t bk = ((uint64_t)(uint32_t)lane_get((int)e.y, TALC_WALK_LEVELS) << 32) | (uint32_t)lane_get((int)e.x, TALC_WALK_LEVELS);
+      const uint64_t bk = ((uint64_t)(uint32_t)lane_get((int)e, TALC_WALK_LEVELS + 1) << 32) | (uint32_t)lane_get((int)e, TALC_WALK_LEVELS);
       if (bk == key) break;
       if (bk == kEmptyKey) { found = false; break; }
       if (++slot == cap) slot = 0;
-      e = *(const v2u32 TALC_AS1*)(wtab + slot * 16 + laneOff);
+      e = wtab[slot * 16 + laneOff];
     }
     if (!found) break;
-    const uint32_t top = e.x, nextw = e.y;
+    const uint32_t top = e & 0xFFFFu, next = (e >> 16) & kWalkNextMask;
     // levels that are "exactly one successor with count >= MIN_COUNT", from level 0 up to the first that is not
-    const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && top >= MINC && (nextw & kWalkNextMask) < MINC);
+    const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && top != kWalkTopNone && top >= MINC && next < MINC);
     int nOK = min(__builtin_ctzll(~passMask), maxSteps - done);
     if (nOK == 0) break;
     // lane j's tip after its step: the current tip shifted by j+1 bases, with the bases of levels 0..j
-    const uint32_t which = (l < TALC_WALK_LEVELS) ? (nextw >> 30) : 0u;
+    const uint32_t which = (l < TALC_WALK_LEVELS) ? (e >> 30) : 0u;
     uint32_t pre = which << (dirRight ? 2 * (TALC_WALK_LEVELS - 1 - lj) : 2 * lj);
     pre |= dpp_row_shr<1>(pre, 0u);
     pre |= dpp_row_shr<2>(pre, 0u);
     pre |= dpp_row_shr<4>(pre, 0u);
+    pre |= dpp_row_shr<8>(pre, 0u);
     uint64_t km;
     if (dirRight) km = ((kmer << (2 * (lj + 1))) | (uint64_t)(pre >> (2 * (TALC_WALK_LEVELS - 1 - lj)))) & kmask;
     else km = ((uint64_t)pre << (2 * (K - 1 - (uint32_t)lj))) | (kmer >> (2 * (lj + 1)));
@@ -1576,6 +1577,14 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     dup |= dpp_row_shr<4>(hv, ~hv) == hv;
     dup |= dpp_row_shr<5>(hv, ~hv) == hv;
     dup |= dpp_row_shr<6>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<7>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<8>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<9>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<10>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<11>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<12>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<13>(hv, ~hv) == hv;
+    static_assert(TALC_WALK_LEVELS == 14, "the lane roles above are written for 14 levels in a 16-lane row");
     // aim / cycle query against the search's filter (init_first_trail entered the aims)
     const int bwi = (int)(hv >> 26);
     const unsigned long long bm = (1ull << ((hv >> 20) & 63u)) | (1ull << ((hv >> 14) & 63u));
@@ -1616,7 +1625,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
 }
 
 TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
-  // the walk tables encode "count >= MIN_COUNT" for MIN_COUNT below 2^30 only (talc_common.h)
+  // the walk tables encode "count >= MIN_COUNT" for MIN_COUNT below 2^14 only (talc_common.h)
   if (uni((int)(X.T.walkRight != nullptr && X.P.MIN_COUNT <= kWalkNextMask)) != 0)
     return uni((int)X.dirRight) ? fast_forward_walk<true>(len, stepCounter, PATH_MAXLENGTH, edge)
                                 : fast_forward_walk<false>(len, stepCounter, PATH_MAXLENGTH, edge);
