@@ -93,6 +93,7 @@ struct talc_batch {
   std::vector<ReadState> h_state;
   std::vector<uint64_t> h_dense_off;
   uint8_t* d_dense = nullptr;
+  uint64_t dense_cap = 0;
   uint64_t* d_dense_off = nullptr;
 };
 
