@@ -2102,7 +2102,7 @@ __global__ void k_pack(const uint8_t* __restrict__ outAll, const uint64_t* __res
 //         posOnRef, score, stop
 // mode 2: wave_find_window(a, pattern=b, wantLast=p3)              -> out[0]
 // mode 4: edit_and_lcs(a, b, needEdit = !p0)                        -> out[0] = edit score (0 if not asked), out[1] = LCS
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, TALC_SEARCH_WAVES_PER_SIMD)   // (same register budget as k_search: they share the step functions)
 k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, int p1, int p2, int p3, int K,
           int* dpG, uint32_t dpCap, int* out, double alpha, double err, int minc) {
   if (lane_id() == 0) memset(&g_X, 0, sizeof g_X);
