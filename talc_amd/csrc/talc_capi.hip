@@ -534,7 +534,7 @@ int talc_batch_fetch_coverage(talc_ctx* c, talc_batch* b, uint32_t* counts, uint
   if (b->n_kmers && (counts || jcounts)) {
     std::vector<uint2> h(b->n_kmers);
     HIPCHK(hipMemcpy(h.data(), b->d_cov, b->n_kmers * sizeof(uint2), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < b->n_kmers; ++i) { if (counts) counts[i] = h[i].x; if (jcounts) jcounts[i] = h[i].y; }
+    for (uint64_t i = 0; i < b->n_kmers; ++i) { if (counts) counts[i] = h[i].x; if (jcounts) jcounts[i] = h[i].y & kCovColourMask; }
   }
   if (kmer_offsets) memcpy(kmer_offsets, b->h_koff.data(), (b->n_reads + 1) * 8);
   if (n_in_kmers && b->n_reads) HIPCHK(hipMemcpy(n_in_kmers, b->d_nin, b->n_reads * 4, hipMemcpyDeviceToHost));

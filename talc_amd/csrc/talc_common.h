@@ -53,6 +53,11 @@ static_assert(sizeof(Bucket) == 32, "bucket must be 32 bytes");
 
 static const uint64_t kEmptyKey = ~0ULL;
 
+// coverage word pair per k-mer position: {count, colour (16 bits) | out-degrees}.  For a k-mer that is in the table
+// (count != 0) k_coverage adds its out-degree towards RIGHT and towards LEFT (0..4 each) and the "known" flag.
+static const uint32_t kCovColourMask = 0xFFFFu, kCovDegKnown = 1u << 22;
+static const int kCovDegRShift = 16, kCovDegLShift = 19;
+
 // Walk table (device only, derived from a finished Bucket table, same capacity and slot order): what a Trail that
 // keeps following its only solid successor will meet over the next WALK_LEVELS steps, in one 64-byte record, so
 // that the single-Trail fast-forward pays one dependent memory access per WALK_LEVELS steps instead of per step.

@@ -171,6 +171,19 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
       maybe = (T.filter[__umul64hi(h, T.filterWords)] & m) == m;
     }
     if (maybe) dev_get_count(T, kmer, c, j);
+    if (c != 0) {
+      // a k-mer of the table: its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this
+      // MIN_COUNT) ride in the colour word's upper half — the anchor search asks for them position by position
+      // (Explorer.cpp:449,515) and would otherwise probe, one dependent access at a time
+      const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
+      BucketRegs br;
+      uint32_t dR = 0, dL = 0;
+      if (probe_bucket(T.right, T.capacity, kmer & m1, br))
+        dR = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
+      if (probe_bucket(T.left, T.capacity, kmer >> 2, br))
+        dL = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
+      j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
+    }
     out[p] = make_uint2(c, j);
     local_in += (c > min_count) ? 1 : 0;
   }

@@ -510,6 +510,7 @@ __shared__ unsigned long long g_prof[PF_N];
 #endif
 
 #define COVX(i) (((const uint2 TALC_AS1*)X.cov)[(i)].x)
+#define COVY(i) (((const uint2 TALC_AS1*)X.cov)[(i)].y)
 
 // DP arrays of the slow paths (sequences longer than the register-resident routines handle):
 // always the per-wave HBM arrays, so no pointer ever mixes LDS and HBM provenance.
@@ -738,21 +739,35 @@ TALC_DN void build_anchors(int side) {
   WSYNC();
   uint32_t nAnc = 0;
   uint32_t firstAnchorPos = 0;
-  for (uint32_t base = 0; base < nPos; base += 64) {   // one recorded position per lane: k-mer and out-degree
+  // out-degree of the k-mer at `pos` (per lane) towards the side's direction: k_coverage left it next to the count for
+  // every k-mer of the table; any other position (count 0: never a recorded one) is probed here
+  const int degDir = (side == 0) ? 1 : 0;
+  const int degShift = (side == 0) ? kCovDegRShift : kCovDegLShift;
+  auto degree_at = [&](bool want, uint32_t pos) -> int {
+    const uint32_t cy = want ? COVY(pos) : kCovDegKnown;
+    int degree = (int)((cy >> degShift) & 7u);
+    const bool unknown = want && !(cy & kCovDegKnown);
+    if (ballot64(unknown) != 0ull) {
+      if (unknown) { uint64_t km, nm; lane_kmer_at(X.read + pos, (int)K, km, nm); degree = dev_out_degree(X.T, MINC, km, nm, degDir); }
+    }
+    return want ? degree : 0;
+  };
+  for (uint32_t base = 0; base < nPos; base += 64) {   // one recorded position per lane
     const uint32_t a = base + (uint32_t)l;
     const bool valid = a < nPos;
     const uint32_t pos = valid ? anchorPos[a] : 0u;
-    uint64_t km = 0, nm = 0;
-    int degree = 0;
-    if (valid) { lane_kmer_at(X.read + pos, (int)K, km, nm); degree = dev_out_degree(X.T, MINC, km, nm, side == 0 ? 1 : 0); }
+    const int degree = degree_at(valid && a != 0, pos);   // (the pivot is taken whatever its degree)
     unsigned long long take = ballot64(valid && ((a == 0) || (degree > 1)));
     while (take != 0ull) {
       const int f = (int)__builtin_ctzll(take);
       take &= take - 1ull;
       // Explorer.cpp:454,520: the recorded count is m_coverage[anc] (loop index), not [anchorPos[anc]]
       if (nAnc < cap) {
-        if (l == f) anc[nAnc] = AnchorRec{km, nm, pos, COVX(a)};
-        if (nAnc == 0) firstAnchorPos = (uint32_t)lane_get((int)pos, f);
+        const uint32_t pf = (uint32_t)lane_get((int)pos, f);
+        uint64_t km, nm;
+        wave_kmer_at(X.read + pf, (int)K, km, nm);
+        if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, COVX(base + (uint32_t)f)};
+        if (nAnc == 0) firstAnchorPos = pf;
         ++nAnc;
       } else X.overflow |= OVF_ANCHORS;
     }
@@ -773,15 +788,16 @@ TALC_DN void build_anchors(int side) {
         const uint32_t idx = visited + (uint32_t)l;
         const bool valid = idx < remaining;
         const uint32_t pos = pivot - 1 - (valid ? idx : 0u);
-        int degree = 0;
-        uint64_t km = 0, nm = 0;
-        if (valid) { lane_kmer_at(X.read + pos, (int)K, km, nm); degree = dev_out_degree(X.T, MINC, km, nm, 1); }
+        const int degree = degree_at(valid, pos);
         unsigned long long branching = ballot64(valid && degree > 1);
         while (branching != 0ull && nAnc < want) {
           const int f = (int)__builtin_ctzll(branching);
           branching &= branching - 1ull;
           if (nAnc < cap) {
-            if (l == f) anc[nAnc] = AnchorRec{km, nm, pos, COVX(pos)};
+            const uint32_t pf = (uint32_t)lane_get((int)pos, f);
+            uint64_t km, nm;
+            wave_kmer_at(X.read + pf, (int)K, km, nm);
+            if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, COVX(pf)};
             ++nAnc;
           } else { X.overflow |= OVF_ANCHORS; full = true; break; }
         }
