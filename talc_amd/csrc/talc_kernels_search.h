@@ -304,15 +304,25 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   const uint32_t Rdeg = min(R, (uint32_t)STRUCT_DEG_CAP);
   for (uint32_t base = 0; base < Rdeg; base += 64) {
     const uint32_t reg = base + l;
-    if (reg < Rdeg) {
+    if (reg < Rdeg) {   // region ends are IN k-mers, i.e. k-mers of the table: k_coverage left their degrees in cov[].y
+      const uint32_t ys = cov[regS[reg]].y, ye = cov[regE[reg]].y;
       uint64_t km, nm;
-      lane_kmer_at(read + regS[reg], (int)K, km, nm);
-      s_degS[reg] = (uint8_t)dev_out_degree(T, MINC, km, nm, 0);
-      lane_kmer_at(read + regE[reg], (int)K, km, nm);
-      s_degE[reg] = (uint8_t)dev_out_degree(T, MINC, km, nm, 1);
+      if (ys & kCovDegKnown) s_degS[reg] = (uint8_t)((ys >> kCovDegLShift) & 7u);
+      else { lane_kmer_at(read + regS[reg], (int)K, km, nm); s_degS[reg] = (uint8_t)dev_out_degree(T, MINC, km, nm, 0); }
+      if (ye & kCovDegKnown) s_degE[reg] = (uint8_t)((ye >> kCovDegRShift) & 7u);
+      else { lane_kmer_at(read + regE[reg], (int)K, km, nm); s_degE[reg] = (uint8_t)dev_out_degree(T, MINC, km, nm, 1); }
     }
   }
   WSYNC();
+
+  // out-degree of the k-mer at a wave-uniform position: from the coverage word when k_coverage knew the k-mer
+  auto degree_of = [&](uint32_t pos, int dirRight) -> int {
+    const uint32_t y = (uint32_t)uni((int)cov[pos].y);
+    if (y & kCovDegKnown) return (int)((y >> (dirRight ? kCovDegRShift : kCovDegLShift)) & 7u);
+    uint64_t km, nm;
+    wave_kmer_at(read + pos, (int)K, km, nm);
+    return dev_out_degree(T, MINC, km, nm, dirRight);
+  };
 
   // ---- analyzeINRegions (Read.cpp:524-600): uniform serial walk over the regions
   // new list is written in place behind a write cursor (nNew <= reg always)
@@ -325,31 +335,28 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
       bool OK = true;
       uint32_t new_start_pos = regS[reg];
       const uint32_t regEnd = regE[reg];
-      uint64_t km, nm;
       const bool lastAndNone = ((R == reg + 1) & (nNew == 0));
       int degStart;
       if (reg < Rdeg && !startMoved) degStart = (int)s_degS[reg];
-      else { wave_kmer_at(read + new_start_pos, (int)K, km, nm); degStart = dev_out_degree(T, MINC, km, nm, 0); }
+      else degStart = degree_of(new_start_pos, 0);
       startMoved = false;
       if (!lastAndNone & (degStart == 0) & (new_start_pos != 0)) {
         OK = false;
         while ((new_start_pos < regEnd) & !OK) {
           ++new_start_pos;
-          wave_kmer_at(read + new_start_pos, (int)K, km, nm);
-          if (dev_out_degree(T, MINC, km, nm, 0) > 1) OK = true;
+          if (degree_of(new_start_pos, 0) > 1) OK = true;
         }
       }
       uint32_t new_end_pos = regEnd;
       if (OK & !lastAndNone) {
         int degEnd;
         if (reg < Rdeg) degEnd = (int)s_degE[reg];
-        else { wave_kmer_at(read + new_end_pos, (int)K, km, nm); degEnd = dev_out_degree(T, MINC, km, nm, 1); }
+        else degEnd = degree_of(new_end_pos, 1);
         if ((degEnd == 0) & (new_end_pos != n - 1)) {
           OK = false;
           while ((new_end_pos > regS[reg]) & !OK) {
             --new_end_pos;
-            wave_kmer_at(read + new_end_pos, (int)K, km, nm);
-            if (dev_out_degree(T, MINC, km, nm, 1) > 1) OK = true;
+            if (degree_of(new_end_pos, 1) > 1) OK = true;
           }
         }
       }
