@@ -907,6 +907,53 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
   return r;
 }
 
+// getSeedAndExtension without the score (the form findStopPosition uses) from a given extension (extCols on the
+// query = the shorter sequence, extRows on the other)
+TALC_D SeedExt seedext_plain(int refLen, int candLen, int extCols, int extRows, int xdrop) {
+  const int K = (int)X.P.K;
+  const int S = X.dirRight ? K - 1 : K;
+  const bool state = !(refLen < candLen);
+  const int qlen = (state ? candLen : refLen) - S, dlen = (state ? refLen : candLen) - S;
+  if (!(qlen > 0 && dlen > 0)) { extCols = 0; extRows = 0; }
+  SeedExt r;
+  r.stop = false; r.score = 0;
+  r.extRef = state ? extRows : extCols;
+  r.extCand = state ? extCols : extRows;
+  r.lenRefExt = S + r.extRef;
+  r.lenHistExt = S + r.extCand;
+  r.posOnRef = X.dirRight ? (S + r.extRef) : (refLen - K - r.extRef);
+  if (!(max(r.lenRefExt, r.lenHistExt) >= K)) { r.score = (-1) * xdrop; r.stop = true; }
+  return r;
+}
+
+// the extensions of getSeedAndExtension for every x-drop in [0, xHi] from one wavefront run (wave_xdrop_wfa_multi):
+// resCols[x], resRows[x] as wave_xdrop_wfa(x) would report them.  false = not available (ask x by x).
+TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xHi, int* resCols,
+                                      int* resRows) {
+  PROF_DECL;
+  refLen = uni(refLen); candLen = uni(candLen); xHi = uni(xHi); ref = uni_ptr(ref); cand = uni_ptr(cand);
+  resCols = (int*)uni_ptr(resCols); resRows = (int*)uni_ptr(resRows);
+  const int K = (int)X.P.K;
+  const int S = X.dirRight ? K - 1 : K;
+  const bool state = !(refLen < candLen);
+  const uint8_t* seq1 = state ? ref : cand; const int len1 = state ? refLen : candLen;
+  const uint8_t* seq2 = state ? cand : ref; const int len2 = state ? candLen : refLen;
+  const int qlen = len2 - S, dlen = len1 - S;
+  if (!(qlen > 0 && dlen > 0) || xHi < 0) return false;
+  PROF_BEGIN();
+  constexpr int STAGE = 3 * LDS_DP_CAP * 4;
+  uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
+  unsigned long long ncells = 0;
+  const int ndiagonals = min(xHi, qlen) + min(xHi, dlen) + 1;
+  int rc = -1;
+  if (ndiagonals <= 63) rc = wave_xdrop_wfa_multi<1>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells);
+  else if (ndiagonals <= 127) rc = wave_xdrop_wfa_multi<2>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells);
+  PROF_END(PF_XDROP);
+  X.cells += ncells;
+  WSYNC();   // lane 0's results are read by every lane
+  return rc >= 0;
+}
+
 // Trail::seedAndExtend (Trail.cpp:193-216) on slot t of set S; returns `ok`
 TALC_DN bool trail_seed_and_extend(int set, int t, int len, int xdrop) {
   WSYNC();   // the Trail's last bases were appended by lane 0: make them visible to the DP lanes
@@ -946,12 +993,21 @@ TALC_DN void record_edge(int set, int t, int len0) {
   // findStopPosition(A, B): `reference` = A, `shorterPath` = B
   const uint8_t* A = shorter ? X.ref : path; const int lenA = shorter ? (int)X.refLen : len;
   const uint8_t* Bq = shorter ? path : X.ref; const int lenB = shorter ? len : (int)X.refLen;
-  nxt = seed_and_extension(A, lenA, Bq, lenB, xdrop1, false);
+  // the loop below asks for x, x-1, x-2, ... : all of them come out of one wavefront run when the band fits
+  int* const resCols = X.dpG;
+  int* const resRows = X.dpG + X.C.dpCap;
+  bool multi = false;
+  if (xdrop1 >= 1 && (uint32_t)(xdrop1 + 1) <= X.C.dpCap) multi = seed_and_extension_multi(A, lenA, Bq, lenB, xdrop1, resCols, resRows);
+  auto ext_at = [&](int x) -> SeedExt {
+    if (multi && x >= 0) return seedext_plain(lenA, lenB, uni(resCols[x]), uni(resRows[x]), x);
+    return seed_and_extension(A, lenA, Bq, lenB, x, false);
+  };
+  nxt = ext_at(xdrop1);
   bool goFurther = true;
   do {
     --xdrop1;
     cur = nxt;
-    nxt = seed_and_extension(A, lenA, Bq, lenB, xdrop1, false);
+    nxt = ext_at(xdrop1);
     if (nxt.lenHistExt < cur.lenHistExt) goFurther = false;
   } while (goFurther & (xdrop1 > 0));
   // score of the retained extension (Trail.cpp:408-434)
@@ -2124,6 +2180,7 @@ __global__ void k_pack(const uint8_t* __restrict__ outAll, const uint64_t* __res
 // mode 1: seed_and_extension(ref=a, cand=b, xdrop, dirRight, true) -> out[0..4] = lenRefExt, lenHistExt,
 //         posOnRef, score, stop
 // mode 2: wave_find_window(a, pattern=b, wantLast=p3)              -> out[0]
+// mode 5: seed_and_extension_multi(a, b, xHi = p0) against seed_and_extension(x) for every x  -> out[0..2]
 // mode 4: edit_and_lcs(a, b, needEdit = !p0)                        -> out[0] = edit score (0 if not asked), out[1] = LCS
 __global__ void __launch_bounds__(64, TALC_SEARCH_WAVES_PER_SIMD)   // (same register budget as k_search: they share the step functions)
 k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, int p1, int p2, int p3, int K,
@@ -2142,6 +2199,23 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
   } else if (mode == 2) {
     const int r = wave_find_window(a, la, b, lb, p3 != 0);
     if (lane_id() == 0) out[0] = r;
+  } else if (mode == 5) {
+    // mode 5: every x in [0, p0] from seed_and_extension_multi against seed_and_extension(x):
+    // out[0] = 1 if the multi form was available, out[1] = number of x that differ, out[2] = the first such x
+    int* rc_ = X.dpG; int* rr_ = X.dpG + X.C.dpCap;
+    const bool ok = seed_and_extension_multi(a, la, b, lb, p0, rc_, rr_);
+    int nbad = 0, first = -1;
+    if (ok) {
+      for (int x = 0; x <= p0; ++x) {
+        const SeedExt m = seedext_plain(la, lb, uni(rc_[x]), uni(rr_[x]), x);
+        const SeedExt e = seed_and_extension(a, la, b, lb, x, false);
+        if (m.lenRefExt != e.lenRefExt || m.lenHistExt != e.lenHistExt || m.posOnRef != e.posOnRef || m.stop != e.stop || m.score != e.score) {
+          if (first < 0) first = x;
+          ++nbad;
+        }
+      }
+    }
+    if (lane_id() == 0) { out[0] = ok ? 1 : 0; out[1] = nbad; out[2] = first; out[5] = (int)X.overflow; }
   } else if (mode == 4) {
     // mode 4: edit_and_lcs(a, b) -> out[0] = global (0,-1,-1) score, out[1] = LCS length
     int es = 0, lcs = 0;

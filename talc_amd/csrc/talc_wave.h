@@ -17,15 +17,29 @@ namespace talc {
 #define WSYNC() __syncthreads()   /* one wave per workgroup: orders the wave's own LDS/global traffic */
 
 TALC_D int lane_id() { return (int)(threadIdx.x & 63u); }
+// whole-wave reductions as DPP VALU ops (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast 15 / 31 across
+// the rows: lane 63 ends up with the result) instead of six ds_bpermute round trips
+#define TALC_WAVE_REDUCE(v, OP, IDENT)                                                                   \
+  do {                                                                                                   \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x111, 0xF, 0xF, false));                            \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x112, 0xF, 0xF, false));                            \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x114, 0xF, 0xF, false));                            \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x118, 0xF, 0xF, false));                            \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x142, 0xA, 0xF, false));                            \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x143, 0xC, 0xF, false));                            \
+  } while (0)
 TALC_D int wave_max_i32(int v) {
-#pragma unroll
+#ifdef TALC_SHFL_REDUCE
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
   return v;
+#endif
+  TALC_WAVE_REDUCE(v, max, INT_MIN);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 TALC_D unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off, 64));
-  return v;
+  int w = (int)(v ^ 0x80000000u);   // order-preserving map to signed
+  TALC_WAVE_REDUCE(w, max, INT_MIN);
+  return (unsigned)__builtin_amdgcn_readlane(w, 63) ^ 0x80000000u;
 }
 TALC_D unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
@@ -381,14 +395,89 @@ TALC_D void wave_edit_lcs_reg(const uint8_t* __restrict__ H_, int n, const uint8
 // not fit the LDS stage (the caller falls back to the anti-diagonal DP).
 TALC_D int lane_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x134, 0xF, 0xF, false); }
 TALC_D int wave_min_i32(int v) {
-#pragma unroll
+#ifdef TALC_SHFL_REDUCE
   for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
   return v;
+#endif
+  TALC_WAVE_REDUCE(v, min, INT_MAX);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 TALC_D unsigned long long lds_load_u64(const uint8_t TALC_AS3* p) {
   unsigned long long v;
   __builtin_memcpy(&v, (const void TALC_AS3*)p, 8);   // any alignment: the LDS runs in unaligned mode
   return v;
+}
+
+// ---- where the anti-diagonal loop of the original stops, and the cell it reports (talc_wfa.h), given the furthest
+// anti-diagonal F and its level E of every diagonal k = kmin + 64 s + lane.  Returns 0 when there is nothing to report.
+template <int NR>
+TALC_D int wfa_select(const int (&F)[NR], const int (&E)[NR], int kmin, int kmax, int qlen, int dlen,
+                      int& extCols, int& extRows, int& extScore) {
+  const int l = lane_id();
+  const int NEG = -(1 << 29);
+  int mF = NEG;
+#pragma unroll
+  for (int s = 0; s < NR; ++s) mF = max(mF, F[s]);
+  const int A = wave_max_i32(mF);
+  const int cols = qlen + 1, rows = dlen + 1;
+  auto minmaxS = [&](int a, bool dropTopBorder, int& mn, int& mx) {
+    int lmn = INT_MAX, lmx = INT_MIN;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int k = kmin + 64 * s + l;
+      const int c = (a + k) >> 1;
+      const bool on = (((k - a) & 1) == 0) & (F[s] >= a) & !(dropTopBorder & (c == a));
+      if (on) { lmn = min(lmn, c); lmx = max(lmx, c); }
+    }
+    mn = wave_min_i32(lmn); mx = wave_max_i32(lmx);
+  };
+  // value of F / E on the wave-uniform diagonal k (must lie in [kmin, kmax])
+  auto at = [&](const int (&r)[NR], int k) -> int {
+    const int j = k - kmin, slot = j >> 6;
+    int v = r[0];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) if (s == slot) v = r[s];
+    return lane_get(v, j & 63);
+  };
+  auto kept = [&](int a, int c) -> bool {
+    const int k = 2 * c - a;
+    if (c < 0 || a - c < 0 || k < kmin || k > kmax) return false;
+    return at(F, k) >= a;
+  };
+  auto take = [&](int a, int c) { extCols = c; extRows = a - c; extScore = -at(E, 2 * c - a); };
+  auto firstMax = [&](int a) -> int {   // least level, then least column, among the diagonals ending on a
+    int key = INT_MAX;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int j = 64 * s + l, k = kmin + j;
+      if ((((k - a) & 1) == 0) & (F[s] == a)) key = min(key, (E[s] << 10) | j);
+    }
+    const int kk = wave_min_i32(key);
+    if (kk == INT_MAX) return 0;
+    const int k = kmin + (kk & 1023);
+    extCols = (a + k) >> 1; extRows = (a - k) >> 1; extScore = -(kk >> 10);
+    return 1;
+  };
+  bool early = false;   // the loop stops one anti-diagonal after A: every successor is outside the matrix
+  if (A + 1 >= 2) {
+    int mn, mx;
+    minmaxS(A, false, mn, mx);
+    const int lo = max(1 + mn, A + 3 - rows), hi = min(2 + mx, cols);
+    early = lo >= hi;
+  }
+  if (!early) return firstMax(A);
+  int maxColA = 1;
+  if (A >= 2) {
+    int mn1, mx1, mn2, mx2;
+    minmaxS(A - 1, true, mn1, mx1);
+    minmaxS(A - 2, false, mn2, mx2);
+    const int cm = max(mx1, mx2);
+    maxColA = (cm == INT_MIN) ? cols : min(2 + cm, cols);
+  }
+  const int c2 = maxColA - 1;
+  if (kept(A, c2)) { take(A, c2); return 1; }
+  if (A >= 2 && kept(A, c2 - 1)) { take(A, c2 - 1); return 1; }
+  return firstMax(A - 1);
 }
 
 template <int NR>
@@ -499,70 +588,131 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   }
   cells += work;
   if (cornerHit) { extCols = qlen; extRows = dlen; extScore = -cornerE; return 1; }
-  // ---- where the anti-diagonal loop of the original stops, and the cell it reports (talc_wfa.h)
-  int mF = NEG;
+  return wfa_select<NR>(F, E, kmin, kmax, qlen, dlen, extCols, extRows, extScore);
+}
+
+// ---- the same extension for EVERY drop-off x in [0, xHi] from one run (findStopPosition, Trajectory.cpp:482-503,
+// asks for x, x-1, x-2, ... until the extension shrinks).  Kept cells are {cost <= x} whatever x is, so the
+// wavefronts of level e are those of any run with x >= e; the one thing that depends on x is the border cell the
+// x-drop leaves uninitialised (|k| = x at anti-diagonal x, for x >= 2): a run with x = e never starts diagonal
+// |k| = e from that cell.  So level e is taken once without that rule (the state larger x continue from), and the
+// result for x = e is selected from a copy in which the two diagonals |k| = e are dropped if that cell was their
+// only way in.  resCols[x] / resRows[x] (global memory, xHi + 1 entries) receive what wave_xdrop_wfa(x) reports.
+// Returns -1 when the band does not fit (the caller then asks x by x).
+template <int NR>
+TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int xHi,
+                                uint8_t TALC_AS3* stage, int stageCap, int* resCols, int* resRows, unsigned long long& cells) {
+  gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
+  const int l = lane_id();
+  qlen = uni(qlen); dlen = uni(dlen); xHi = uni(xHi);
+  if (qlen <= 0 || dlen <= 0 || xHi < 0) return -1;
+  const int NEG = -(1 << 29);
+  const int X = min(xHi, 1 << 20);
+  const int kmin = -min(X, dlen), kmax = min(X, qlen);
+  const int nd = kmax - kmin + 1;
+  if (nd > 64 * NR - 1) return -1;
+  const int qS = min(qlen, dlen + X), dS = min(dlen, qlen + X);
+  const int qpad = (qS + 16) & ~7;
+  if (qpad + dS + 16 > stageCap) return -1;
+  for (int i = l; i < qS; i += 64) stage[i] = querySeg[i];
+  for (int i = l; i < dS; i += 64) stage[qpad + i] = dbSeg[i];
+  if (l == 0) { stage[qS] = 0xF0; stage[qpad + dS] = 0xF1; }
+  WSYNC();
+  const int corner = qlen + dlen;
+  int F[NR], E[NR], amax[NR], ak[NR];
 #pragma unroll
-  for (int s = 0; s < NR; ++s) mF = max(mF, F[s]);
-  const int A = wave_max_i32(mF);
-  const int cols = qlen + 1, rows = dlen + 1;
-  auto minmaxS = [&](int a, bool dropTopBorder, int& mn, int& mx) {
-    int lmn = INT_MAX, lmx = INT_MIN;
+  for (int s = 0; s < NR; ++s) {
+    const int j = 64 * s + l, k = kmin + j;
+    ak[s] = k < 0 ? -k : k;
+    amax[s] = (j < nd) ? min(2 * qlen - k, 2 * dlen + k) : NEG;
+    F[s] = NEG; E[s] = 0;
+  }
+  auto extend = [&](int (&a)[NR], bool (&act)[NR]) {
+    unsigned qa[NR], da[NR];
+    bool any = false;
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
       const int k = kmin + 64 * s + l;
-      const int c = (a + k) >> 1;
-      const bool on = (((k - a) & 1) == 0) & (F[s] >= a) & !(dropTopBorder & (c == a));
-      if (on) { lmn = min(lmn, c); lmx = max(lmx, c); }
+      qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
+      any |= act[s];
     }
-    mn = wave_min_i32(lmn); mx = wave_max_i32(lmx);
-  };
-  // value of F / E on the wave-uniform diagonal k (must lie in [kmin, kmax])
-  auto at = [&](const int (&r)[NR], int k) -> int {
-    const int j = k - kmin, slot = j >> 6;
-    int v = r[0];
+    while (ballot64(any) != 0ull) {
+      any = false;
 #pragma unroll
-    for (int s = 0; s < NR; ++s) if (s == slot) v = r[s];
-    return lane_get(v, j & 63);
+      for (int s = 0; s < NR; ++s) {
+        if (act[s]) {
+          const unsigned long long w = lds_load_u64(stage + qa[s]) ^ lds_load_u64(stage + da[s]);
+          if (w == 0ull) { qa[s] += 8; da[s] += 8; a[s] += 16; any = true; }
+          else { a[s] += 2 * (__builtin_ctzll(w) >> 3); act[s] = false; }
+        }
+      }
+    }
   };
-  auto kept = [&](int a, int c) -> bool {
-    const int k = 2 * c - a;
-    if (c < 0 || a - c < 0 || k < kmin || k > kmax) return false;
-    return at(F, k) >= a;
+  auto hits = [&](const int (&f)[NR]) -> bool {
+    unsigned long long hit = 0;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) hit |= ballot64(f[s] == corner);
+    return hit != 0ull;
   };
-  auto take = [&](int a, int c) { extCols = c; extRows = a - c; extScore = -at(E, 2 * c - a); };
-  auto firstMax = [&](int a) -> int {   // least level, then least column, among the diagonals ending on a
-    int key = INT_MAX;
+  auto emit_corner_from = [&](int xFrom) {   // every x >= xFrom reaches the far corner
+    for (int x = xFrom + l; x <= xHi; x += 64) { resCols[x] = qlen; resRows[x] = dlen; }
+  };
+  auto emit_selected = [&](int x, const int (&f)[NR], const int (&lev)[NR]) {
+    int c = 0, r = 0, sc = 0;
+    if (!wfa_select<NR>(f, lev, kmin, kmax, qlen, dlen, c, r, sc)) { c = 0; r = 0; }
+    if (l == 0) { resCols[x] = c; resRows[x] = r; }
+  };
+  {
+    int a0[NR]; bool act0[NR];
+    const int j0 = -kmin;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) { a0[s] = 0; act0[s] = (64 * s + l == j0); }
+    extend(a0, act0);
+#pragma unroll
+    for (int s = 0; s < NR; ++s) if (64 * s + l == j0) F[s] = a0[s];
+  }
+  unsigned long long work = 0;
+  if (hits(F)) { emit_corner_from(0); return 1; }
+  emit_selected(0, F, E);
+  for (int e = 1; e <= xHi; ++e) {
+    int rotR[NR], rotL[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) { rotR[s] = lane_ror1(F[s]); rotL[s] = lane_rol1(F[s]); }
+    const int sLo = max(0, -e - kmin) >> 6, sHi = min(nd - 1, e - kmin) >> 6;
+    int b[NR]; bool act[NR], borderOnly[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
-      const int j = 64 * s + l, k = kmin + j;
-      if ((((k - a) & 1) == 0) & (F[s] == a)) key = min(key, (E[s] << 10) | j);
+      b[s] = NEG; act[s] = false; borderOnly[s] = false;
+      if (NR == 1 || (s >= sLo && s <= sHi)) {
+        const int fl = (NR > 1 && l == 0) ? rotR[(s + NR - 1) % NR] : rotR[s];   // diagonal k-1
+        const int fr = (NR > 1 && l == 63) ? rotL[(s + 1) % NR] : rotL[s];       // diagonal k+1
+        int v2 = fl + 1; v2 = (v2 <= amax[s]) ? v2 : NEG;
+        int v3 = fr + 1; v3 = (v3 <= amax[s]) ? v3 : NEG;
+        const int v = max(max(v2, v3), min(F[s] + 2, amax[s]));
+        borderOnly[s] = (e >= 2) & (ak[s] == e) & (v == e);   // what a run with x = e turns into "no cell"
+        b[s] = v;
+        act[s] = (v > F[s]) & (v >= 0);
+      }
     }
-    const int kk = wave_min_i32(key);
-    if (kk == INT_MAX) return 0;
-    const int k = kmin + (kk & 1023);
-    extCols = (a + k) >> 1; extRows = (a - k) >> 1; extScore = -(kk >> 10);
-    return 1;
-  };
-  bool early = false;   // the loop stops one anti-diagonal after A: every successor is outside the matrix
-  if (A + 1 >= 2) {
-    int mn, mx;
-    minmaxS(A, false, mn, mx);
-    const int lo = max(1 + mn, A + 3 - rows), hi = min(2 + mx, cols);
-    early = lo >= hi;
+    bool moved[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) moved[s] = act[s];
+    extend(b, act);
+    int Fx[NR], Ex[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int fOld = F[s], eOld = E[s];
+      if (moved[s]) { F[s] = b[s]; E[s] = e; }
+      Fx[s] = borderOnly[s] ? fOld : F[s];
+      Ex[s] = borderOnly[s] ? eOld : E[s];
+    }
+    work += (unsigned long long)min(nd, 2 * e + 1);
+    if (hits(Fx)) { if (l == 0) { resCols[e] = qlen; resRows[e] = dlen; } }
+    else emit_selected(e, Fx, Ex);
+    if (hits(F)) { emit_corner_from(e + 1); break; }
   }
-  if (!early) return firstMax(A);
-  int maxColA = 1;
-  if (A >= 2) {
-    int mn1, mx1, mn2, mx2;
-    minmaxS(A - 1, true, mn1, mx1);
-    minmaxS(A - 2, false, mn2, mx2);
-    const int cm = max(mx1, mx2);
-    maxColA = (cm == INT_MIN) ? cols : min(2 + cm, cols);
-  }
-  const int c2 = maxColA - 1;
-  if (kept(A, c2)) { take(A, c2); return 1; }
-  if (A >= 2 && kept(A, c2 - 1)) { take(A, c2 - 1); return 1; }
-  return firstMax(A - 1);
+  cells += work;
+  return 1;
 }
 
 // ------------------------------------------------------------------ global distances as wavefronts

@@ -185,6 +185,45 @@ def test_device_seed_and_extension_matches_oracle(gpu_pair):
                 (n, len(cand), xdrop, direction)
 
 
+def test_device_multi_xdrop_run_equals_the_single_runs(gpu_pair):
+    """findStopPosition asks for x, x-1, x-2, ...: seed_and_extension_multi takes all of [0, x] from one wavefront run.
+    On the device, every x of that run against the single-x routine (itself pinned to the oracle above): similar and
+    unrelated pairs, both directions, prefixes / overhangs, runs that reach the far corner, x up to 60."""
+    rnd = random.Random(44)
+    ctx = gpu_pair.ctx
+    used = 0
+    for it in range(160):
+        n = rnd.choice([21, 22, 25, 30, 60, 120, 300, 700])
+        ref = [rnd.choice("ACGT") for _ in range(n)]
+        cand = list(ref)
+        for _ in range(rnd.choice([0, 1, 2, 5, 12, 30])):
+            p = rnd.randrange(len(cand))
+            x = rnd.random()
+            if x < 0.4:
+                cand[p] = rnd.choice("ACGT")
+            elif x < 0.7:
+                cand.insert(p, rnd.choice("ACGT"))
+            elif len(cand) > 25:
+                del cand[p]
+        r = rnd.random()
+        if r < 0.3:
+            cand = cand[: max(21, rnd.randrange(len(cand) + 1))]
+        elif r < 0.6:
+            cand = cand + [rnd.choice("ACGT") for _ in range(rnd.randint(1, 40))]
+        if rnd.random() < 0.1:
+            cand = cand[:21] + [rnd.choice("ACGT") for _ in range(rnd.randint(0, 80))]
+        ref, cand = "".join(ref), "".join(cand)
+        x_hi = rnd.choice([1, 2, 3, 5, 8, 13, 21, 31, 32, 45, 60])
+        for direction in (0, 1):
+            a, b = (ref, cand) if direction else (ref[::-1], cand[::-1])
+            got = ctx.test_dp(5, a, b, x_hi, direction)
+            assert got[5] == 0
+            if got[0]:
+                used += 1
+                assert got[1] == 0, (n, len(cand), x_hi, direction, "first differing x", int(got[2]))
+    assert used > 250
+
+
 def test_device_window_search(gpu_pair):
     rnd = random.Random(5)
     ctx = gpu_pair.ctx
