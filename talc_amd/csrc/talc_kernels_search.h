@@ -134,7 +134,13 @@ TALC_D void wave_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, u
   nmask = ballot64((l < K) && (c > 3u));
   uint64_t v = (l < K) ? ((uint64_t)(c & 3u) << (2 * (K - 1 - l))) : 0ull;
   if (c > 3u) v = 0;
-  v = ((uint64_t)wave_or_u32((uint32_t)(v >> 32)) << 32) | wave_or_u32((uint32_t)v);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo |= (uint32_t)__shfl_xor((int)lo, off, 64);
+    hi |= (uint32_t)__shfl_xor((int)hi, off, 64);
+    v = ((uint64_t)hi << 32) | lo;
+  }
   kmer = v;
 }
 
@@ -920,47 +926,32 @@ TALC_D SeedExt seedext_plain(int refLen, int candLen, int extCols, int extRows, 
   return r;
 }
 
-// the extensions of getSeedAndExtension for every x-drop in [0, xHi] from one wavefront run (wave_xdrop_wfa_multi;
-// its per-x states live in the wave's DP scratch): MultiX::ok = false means not available (ask x by x).
-struct MultiX { bool ok; int nr, qlen, dlen, xHi; };
-TALC_DN MultiX seed_and_extension_multi(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xHi) {
+// the extensions of getSeedAndExtension for every x-drop in [0, xHi] from one wavefront run (wave_xdrop_wfa_multi):
+// resCols[x], resRows[x] as wave_xdrop_wfa(x) would report them.  false = not available (ask x by x).
+TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xHi, int* resCols,
+                                      int* resRows) {
   PROF_DECL;
   refLen = uni(refLen); candLen = uni(candLen); xHi = uni(xHi); ref = uni_ptr(ref); cand = uni_ptr(cand);
+  resCols = (int*)uni_ptr(resCols); resRows = (int*)uni_ptr(resRows);
   const int K = (int)X.P.K;
   const int S = X.dirRight ? K - 1 : K;
   const bool state = !(refLen < candLen);
   const uint8_t* seq1 = state ? ref : cand; const int len1 = state ? refLen : candLen;
   const uint8_t* seq2 = state ? cand : ref; const int len2 = state ? candLen : refLen;
-  MultiX m;
-  m.ok = false; m.nr = 0; m.qlen = len2 - S; m.dlen = len1 - S; m.xHi = xHi;
-  if (!(m.qlen > 0 && m.dlen > 0) || xHi < 0) return m;
-  const int ndiagonals = min(xHi, m.qlen) + min(xHi, m.dlen) + 1;
-  m.nr = ndiagonals <= 63 ? 1 : (ndiagonals <= 127 ? 2 : 0);
-  if (m.nr == 0 || (uint64_t)(xHi + 1) * 64ull * (uint64_t)m.nr > (uint64_t)X.C.dpCap) return m;
+  const int qlen = len2 - S, dlen = len1 - S;
+  if (!(qlen > 0 && dlen > 0) || xHi < 0) return false;
   PROF_BEGIN();
   constexpr int STAGE = 3 * LDS_DP_CAP * 4;
   uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
   unsigned long long ncells = 0;
-  int* snapF = X.dpG; int* snapE = X.dpG + X.C.dpCap; int* flags = X.dpG + 2ull * X.C.dpCap;
-  int rc;
-  if (m.nr == 1) rc = wave_xdrop_wfa_multi<1>(seq2 + S, m.qlen, seq1 + S, m.dlen, xHi, stage, STAGE, snapF, snapE, flags, ncells);
-  else rc = wave_xdrop_wfa_multi<2>(seq2 + S, m.qlen, seq1 + S, m.dlen, xHi, stage, STAGE, snapF, snapE, flags, ncells);
+  const int ndiagonals = min(xHi, qlen) + min(xHi, dlen) + 1;
+  int rc = -1;
+  if (ndiagonals <= 63) rc = wave_xdrop_wfa_multi<1>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells);
+  else if (ndiagonals <= 127) rc = wave_xdrop_wfa_multi<2>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells);
   PROF_END(PF_XDROP);
   X.cells += ncells;
-  WSYNC();   // the flags are written by some lanes and read by all
-  m.ok = rc >= 0;
-  return m;
-}
-// getSeedAndExtension(x) (score-less form) out of that run
-TALC_D SeedExt seed_and_extension_at(const MultiX& m, int refLen, int candLen, int x) {
-  PROF_DECL;
-  PROF_BEGIN();
-  const int* snapF = X.dpG; const int* snapE = X.dpG + X.C.dpCap; const int* flags = X.dpG + 2ull * X.C.dpCap;
-  int c = 0, r = 0;
-  if (m.nr == 1) wfa_multi_at<1>(snapF, snapE, flags, x, m.xHi, m.qlen, m.dlen, c, r);
-  else wfa_multi_at<2>(snapF, snapE, flags, x, m.xHi, m.qlen, m.dlen, c, r);
-  PROF_END(PF_XDROP);
-  return seedext_plain(refLen, candLen, c, r, x);
+  WSYNC();   // lane 0's results are read by every lane
+  return rc >= 0;
 }
 
 // Trail::seedAndExtend (Trail.cpp:193-216) on slot t of set S; returns `ok`
@@ -1003,11 +994,12 @@ TALC_DN void record_edge(int set, int t, int len0) {
   const uint8_t* A = shorter ? X.ref : path; const int lenA = shorter ? (int)X.refLen : len;
   const uint8_t* Bq = shorter ? path : X.ref; const int lenB = shorter ? len : (int)X.refLen;
   // the loop below asks for x, x-1, x-2, ... : all of them come out of one wavefront run when the band fits
-  MultiX mx;
-  mx.ok = false;
-  if (xdrop1 >= 1) mx = seed_and_extension_multi(A, lenA, Bq, lenB, xdrop1);
+  int* const resCols = X.dpG;
+  int* const resRows = X.dpG + X.C.dpCap;
+  bool multi = false;
+  if (xdrop1 >= 1 && (uint32_t)(xdrop1 + 1) <= X.C.dpCap) multi = seed_and_extension_multi(A, lenA, Bq, lenB, xdrop1, resCols, resRows);
   auto ext_at = [&](int x) -> SeedExt {
-    if (mx.ok && x >= 0) return seed_and_extension_at(mx, lenA, lenB, x);
+    if (multi && x >= 0) return seedext_plain(lenA, lenB, uni(resCols[x]), uni(resRows[x]), x);
     return seed_and_extension(A, lenA, Bq, lenB, x, false);
   };
   nxt = ext_at(xdrop1);
@@ -2210,14 +2202,12 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
   } else if (mode == 5) {
     // mode 5: every x in [0, p0] from seed_and_extension_multi against seed_and_extension(x):
     // out[0] = 1 if the multi form was available, out[1] = number of x that differ, out[2] = the first such x
-    // (for these sizes the single-x routine keeps its band in registers / LDS: it does not touch the DP scratch the
-    //  multi-x states live in)
-    const MultiX mx = seed_and_extension_multi(a, la, b, lb, p0);
-    const bool ok = mx.ok;
+    int* rc_ = X.dpG; int* rr_ = X.dpG + X.C.dpCap;
+    const bool ok = seed_and_extension_multi(a, la, b, lb, p0, rc_, rr_);
     int nbad = 0, first = -1;
     if (ok) {
       for (int x = 0; x <= p0; ++x) {
-        const SeedExt m = seed_and_extension_at(mx, la, lb, x);
+        const SeedExt m = seedext_plain(la, lb, uni(rc_[x]), uni(rr_[x]), x);
         const SeedExt e = seed_and_extension(a, la, b, lb, x, false);
         if (m.lenRefExt != e.lenRefExt || m.lenHistExt != e.lenHistExt || m.posOnRef != e.posOnRef || m.stop != e.stop || m.score != e.score) {
           if (first < 0) first = x;

@@ -29,14 +29,12 @@ TALC_D int lane_id() { return (int)(threadIdx.x & 63u); }
     v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x143, 0xC, 0xF, false));                            \
   } while (0)
 TALC_D int wave_max_i32(int v) {
+#ifdef TALC_SHFL_REDUCE
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+#endif
   TALC_WAVE_REDUCE(v, max, INT_MIN);
   return __builtin_amdgcn_readlane(v, 63);
-}
-TALC_D int talc_or_i32(int a, int b) { return a | b; }
-TALC_D unsigned wave_or_u32(unsigned v) {
-  int w = (int)v;
-  TALC_WAVE_REDUCE(w, talc_or_i32, 0);
-  return (unsigned)__builtin_amdgcn_readlane(w, 63);
 }
 TALC_D unsigned wave_max_u32(unsigned v) {
   int w = (int)(v ^ 0x80000000u);   // order-preserving map to signed
@@ -397,6 +395,10 @@ TALC_D void wave_edit_lcs_reg(const uint8_t* __restrict__ H_, int n, const uint8
 // not fit the LDS stage (the caller falls back to the anti-diagonal DP).
 TALC_D int lane_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x134, 0xF, 0xF, false); }
 TALC_D int wave_min_i32(int v) {
+#ifdef TALC_SHFL_REDUCE
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+#endif
   TALC_WAVE_REDUCE(v, min, INT_MAX);
   return __builtin_amdgcn_readlane(v, 63);
 }
@@ -599,7 +601,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 // Returns -1 when the band does not fit (the caller then asks x by x).
 template <int NR>
 TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int xHi,
-                                uint8_t TALC_AS3* stage, int stageCap, int* snapF, int* snapE, int* flags, unsigned long long& cells) {
+                                uint8_t TALC_AS3* stage, int stageCap, int* resCols, int* resRows, unsigned long long& cells) {
   gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
   qlen = uni(qlen); dlen = uni(dlen); xHi = uni(xHi);
@@ -653,12 +655,12 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
     return hit != 0ull;
   };
   auto emit_corner_from = [&](int xFrom) {   // every x >= xFrom reaches the far corner
-    for (int x = xFrom + l; x <= xHi; x += 64) flags[x] = 1;
+    for (int x = xFrom + l; x <= xHi; x += 64) { resCols[x] = qlen; resRows[x] = dlen; }
   };
-  auto emit_selected = [&](int x, const int (&f)[NR], const int (&lev)[NR]) {   // the state wfa_multi_at(x) selects from
-#pragma unroll
-    for (int s = 0; s < NR; ++s) { snapF[(x * NR + s) * 64 + l] = f[s]; snapE[(x * NR + s) * 64 + l] = lev[s]; }
-    if (l == 0) flags[x] = 0;
+  auto emit_selected = [&](int x, const int (&f)[NR], const int (&lev)[NR]) {
+    int c = 0, r = 0, sc = 0;
+    if (!wfa_select<NR>(f, lev, kmin, kmax, qlen, dlen, c, r, sc)) { c = 0; r = 0; }
+    if (l == 0) { resCols[x] = c; resRows[x] = r; }
   };
   {
     int a0[NR]; bool act0[NR];
@@ -705,27 +707,12 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
       Ex[s] = borderOnly[s] ? eOld : E[s];
     }
     work += (unsigned long long)min(nd, 2 * e + 1);
-    if (hits(Fx)) { if (l == 0) flags[e] = 1; }
+    if (hits(Fx)) { if (l == 0) { resCols[e] = qlen; resRows[e] = dlen; } }
     else emit_selected(e, Fx, Ex);
     if (hits(F)) { emit_corner_from(e + 1); break; }
   }
   cells += work;
   return 1;
-}
-
-template <int NR>
-TALC_D void wfa_multi_at(const int* snapF, const int* snapE, const int* flags, int x, int xHi, int qlen, int dlen,
-                         int& extCols, int& extRows) {
-  const int l = lane_id();
-  if (uni(flags[x]) != 0) { extCols = qlen; extRows = dlen; return; }
-  const int X = min(xHi, 1 << 20);
-  const int kmin = -min(X, dlen), kmax = min(X, qlen);
-  int F[NR], E[NR];
-#pragma unroll
-  for (int s = 0; s < NR; ++s) { F[s] = snapF[(x * NR + s) * 64 + l]; E[s] = snapE[(x * NR + s) * 64 + l]; }
-  int c = 0, r = 0, sc = 0;
-  if (!wfa_select<NR>(F, E, kmin, kmax, qlen, dlen, c, r, sc)) { c = 0; r = 0; }
-  extCols = c; extRows = r;
 }
 
 // ------------------------------------------------------------------ global distances as wavefronts
