@@ -134,13 +134,7 @@ TALC_D void wave_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, u
   nmask = ballot64((l < K) && (c > 3u));
   uint64_t v = (l < K) ? ((uint64_t)(c & 3u) << (2 * (K - 1 - l))) : 0ull;
   if (c > 3u) v = 0;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo |= (uint32_t)__shfl_xor((int)lo, off, 64);
-    hi |= (uint32_t)__shfl_xor((int)hi, off, 64);
-    v = ((uint64_t)hi << 32) | lo;
-  }
+  v = ((uint64_t)wave_or_u32((uint32_t)(v >> 32)) << 32) | wave_or_u32((uint32_t)v);
   kmer = v;
 }
 

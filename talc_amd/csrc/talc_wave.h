@@ -29,12 +29,14 @@ TALC_D int lane_id() { return (int)(threadIdx.x & 63u); }
     v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x143, 0xC, 0xF, false));                            \
   } while (0)
 TALC_D int wave_max_i32(int v) {
-#ifdef TALC_SHFL_REDUCE
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
-#endif
   TALC_WAVE_REDUCE(v, max, INT_MIN);
   return __builtin_amdgcn_readlane(v, 63);
+}
+TALC_D int talc_or_i32(int a, int b) { return a | b; }
+TALC_D unsigned wave_or_u32(unsigned v) {
+  int w = (int)v;
+  TALC_WAVE_REDUCE(w, talc_or_i32, 0);
+  return (unsigned)__builtin_amdgcn_readlane(w, 63);
 }
 TALC_D unsigned wave_max_u32(unsigned v) {
   int w = (int)(v ^ 0x80000000u);   // order-preserving map to signed
@@ -395,10 +397,6 @@ TALC_D void wave_edit_lcs_reg(const uint8_t* __restrict__ H_, int n, const uint8
 // not fit the LDS stage (the caller falls back to the anti-diagonal DP).
 TALC_D int lane_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x134, 0xF, 0xF, false); }
 TALC_D int wave_min_i32(int v) {
-#ifdef TALC_SHFL_REDUCE
-  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
-#endif
   TALC_WAVE_REDUCE(v, min, INT_MAX);
   return __builtin_amdgcn_readlane(v, 63);
 }
