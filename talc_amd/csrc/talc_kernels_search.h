@@ -544,9 +544,15 @@ TALC_DN int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int mat
 // needEdit = false: only the LCS is wanted (the caller does not use the edit score: a single bridge candidate is not
 // compared with anything, Trajectory.cpp:282-303; an edge whose extension stopped takes the extension's own score,
 // Trail.cpp:408-434) — editScore is then left at 0.
-TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, int& editScore, int& lcsLen, bool needEdit_) {
+// acceptLcs > 0 (with needEdit = false): the caller only asks whether the LCS reaches acceptLcs (a threshold test,
+// Explorer.cpp:973) — lcsLen is then either the exact LCS or, as soon as the wavefront proves LCS >= acceptLcs,
+// acceptLcs itself.
+TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, int& editScore, int& lcsLen, bool needEdit_,
+                          int acceptLcs_) {
   la = uni(la); lb = uni(lb);
   const bool needEdit = uni((int)needEdit_) != 0;
+  const int acceptLcs = uni(acceptLcs_);
+  const int acceptA = (!needEdit && acceptLcs > 0) ? 2 * acceptLcs : INT_MAX;
   const uint8_t* a = uni_ptr(a_); const uint8_t* b = uni_ptr(b_);
   if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
   // both measures as wavefronts over the two sequences staged in LDS: the levels needed are the edit distance, and
@@ -579,11 +585,12 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
         else if (hi <= 127) d = wave_wfa_global<4, false>(stage, qpad, la, lb, ncells);
       }
     } else {   // no bound from the edit distance: narrowest wavefront first (-1 = it needs more levels than that width holds)
-      if (lo <= 31 && la <= 220) d = wave_wfa_global<1, false>(stage, qpad, la, lb, ncells);
-      if (d < 0 && lo <= 63 && la <= 440) d = wave_wfa_global<2, false>(stage, qpad, la, lb, ncells);
-      if (d < 0 && lo <= 127) d = wave_wfa_global<4, false>(stage, qpad, la, lb, ncells);
+      if (lo <= 31 && la <= 220) d = wave_wfa_global<1, false>(stage, qpad, la, lb, ncells, acceptA);
+      if (d == -1 && lo <= 63 && la <= 440) d = wave_wfa_global<2, false>(stage, qpad, la, lb, ncells, acceptA);
+      if (d == -1 && lo <= 127) d = wave_wfa_global<4, false>(stage, qpad, la, lb, ncells, acceptA);
     }
     if (d >= 0) { lcsLen = (la + lb - d) >> 1; haveLcs = true; }
+    else if (d == -2) { lcsLen = acceptLcs; haveLcs = true; }   // proven: LCS >= acceptLcs
     X.cells += ncells;
     WSYNC();
   }
@@ -1012,7 +1019,7 @@ TALC_DN void record_edge(int set, int t, int len0) {
     // score of the retained extension (Trail.cpp:408-434) and computePercentID (Trajectory.cpp:505-528):
     // -edit distance and LCS / max length of the same two extensions
     int es, lcs;
-    edit_and_lcs(A, cur.lenRefExt, Bq, cur.lenHistExt, es, lcs, !cur.stop);
+    edit_and_lcs(A, cur.lenRefExt, Bq, cur.lenHistExt, es, lcs, !cur.stop, 0);
     score = cur.stop ? (double)cur.score : (double)es;
     const double lenMax = (double)max(cur.lenRefExt, cur.lenHistExt);
     idscore = (double)lcs / lenMax;
@@ -1812,7 +1819,17 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
         double score, idv;
         // computeEditDistance / computeIDScore (Trajectory.cpp:386-428, 337-384): both non-empty here
         int es, lcs;
-        edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs, X.nFull > 1);   // one candidate: its score is never compared
+        // one candidate: its score is never compared, and its identity only with MIN_INNER (Explorer.cpp:973): the
+        // least LCS that passes, T, is enough — lcs >= T  <=>  (double)lcs / maxLen >= MIN_INNER (monotone in lcs)
+        int accept = 0;
+        if (X.nFull == 1 && P.MIN_INNER > 0.0) {
+          const double mxl = (double)max(X.refLen, fm.len);
+          int T = (int)ceil(P.MIN_INNER * mxl);
+          while (T > 1 && (double)(T - 1) / mxl >= P.MIN_INNER) --T;
+          while ((double)T / mxl < P.MIN_INNER) ++T;
+          accept = T;
+        }
+        edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs, X.nFull > 1, accept);
         score = (double)es;
         idv = (double)lcs / (double)max(X.refLen, fm.len);
         // cutAnchors INNER (Trajectory.cpp:176-197)
@@ -2175,7 +2192,7 @@ __global__ void k_pack(const uint8_t* __restrict__ outAll, const uint64_t* __res
 //         posOnRef, score, stop
 // mode 2: wave_find_window(a, pattern=b, wantLast=p3)              -> out[0]
 // mode 5: seed_and_extension_multi(a, b, xHi = p0) against seed_and_extension(x) for every x  -> out[0..2]
-// mode 4: edit_and_lcs(a, b, needEdit = !p0)                        -> out[0] = edit score (0 if not asked), out[1] = LCS
+// mode 4: edit_and_lcs(a, b, needEdit = !p0, acceptLcs = p1 if p0 == 2) -> out[0] = edit score (0 if not asked), out[1] = LCS
 __global__ void __launch_bounds__(64, TALC_SEARCH_WAVES_PER_SIMD)   // (same register budget as k_search: they share the step functions)
 k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, int p1, int p2, int p3, int K,
           int* dpG, uint32_t dpCap, int* out, double alpha, double err, int minc) {
@@ -2213,7 +2230,7 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
   } else if (mode == 4) {
     // mode 4: edit_and_lcs(a, b) -> out[0] = global (0,-1,-1) score, out[1] = LCS length
     int es = 0, lcs = 0;
-    edit_and_lcs(a, la, b, lb, es, lcs, p0 == 0);
+    edit_and_lcs(a, la, b, lb, es, lcs, p0 == 0, p0 == 2 ? p1 : 0);
     if (lane_id() == 0) { out[0] = es; out[1] = lcs; out[5] = (int)X.overflow; }
   } else {
     // mode 3: tag_next_nodes on the device.  a = 4 counts + 4 colours + count as 9 little-endian u32 (36 bytes),

@@ -720,8 +720,11 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
 // distance qlen + dlen - 2 LCS (LCS = the localAlignment(1,0,0) optimum of Trajectory.cpp:368,525).
 // Same lane layout and level step as wave_xdrop_wfa, no drop-off: the levels run until the far corner
 // is reached.  Returns -1 if that takes more than 32*NR-1 levels (the diagonals no longer fit the lanes).
+// acceptA (without SUBST only): a path that has reached anti-diagonal a with e insertions/deletions has matched
+// (a - e) / 2 bases, a lower bound of the LCS; as soon as some diagonal has a - e >= acceptA the routine returns -2
+// ("the LCS is at least acceptA / 2") instead of running on to the corner.  INT_MAX = never.
 template <int NR, bool SUBST>
-TALC_D int wave_wfa_global(const uint8_t TALC_AS3* stage, int qpad, int qlen, int dlen, unsigned long long& cells) {
+TALC_D int wave_wfa_global(const uint8_t TALC_AS3* stage, int qpad, int qlen, int dlen, unsigned long long& cells, int acceptA = INT_MAX) {
   const int l = lane_id();
   const int NEG = -(1 << 29);
   const int E = 32 * NR - 1;
@@ -767,10 +770,11 @@ TALC_D int wave_wfa_global(const uint8_t TALC_AS3* stage, int qpad, int qlen, in
     for (int s = 0; s < NR; ++s) if (64 * s + l == j0) F[s] = a0[s];
   }
   {
-    unsigned long long hit = 0;
+    unsigned long long hit = 0, acc = 0;
 #pragma unroll
-    for (int s = 0; s < NR; ++s) hit |= ballot64(F[s] == corner);
+    for (int s = 0; s < NR; ++s) { hit |= ballot64(F[s] == corner); if (!SUBST) acc |= ballot64(F[s] >= acceptA); }
     if (hit != 0ull) return 0;
+    if (!SUBST && acc != 0ull) return -2;
   }
   unsigned long long work = 0;
   int result = -1;
@@ -798,14 +802,16 @@ TALC_D int wave_wfa_global(const uint8_t TALC_AS3* stage, int qpad, int qlen, in
 #pragma unroll
     for (int s = 0; s < NR; ++s) moved[s] = act[s];
     extend(b, act);
-    unsigned long long hit = 0;
+    unsigned long long hit = 0, acc = 0;
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
       if (moved[s]) F[s] = b[s];
       hit |= ballot64(F[s] == corner);
+      if (!SUBST) acc |= ballot64(F[s] - e >= acceptA);
     }
     work += (unsigned long long)min(nd, 2 * e + 1);
     if (hit != 0ull) { result = e; break; }
+    if (!SUBST && acc != 0ull) { result = -2; break; }
   }
   cells += work;
   return result;

@@ -146,6 +146,11 @@ def test_device_edit_distance_and_lcs_match_oracle(gpu_pair):
         assert got[5] == 0 and (got[0], got[1]) == (exp_e, exp_l), (len(a), len(b), got[:2].tolist(), exp_e, exp_l)
         got = ctx.test_dp(4, a, b, p0=1)     # LCS only (the form used when the edit score is not needed)
         assert got[5] == 0 and (got[0], got[1]) == (0, exp_l), (len(a), len(b), got[:2].tolist(), exp_l)
+        # threshold form: "is the LCS at least t" may stop early with t itself, and only when that is true
+        for t in {max(1, exp_l - 3), exp_l, exp_l + 1, max(1, (7 * max(len(a), len(b)) + 9) // 10), 1}:
+            got = ctx.test_dp(4, a, b, p0=2, p1=t)
+            assert got[5] == 0 and got[0] == 0
+            assert got[1] == exp_l or (got[1] == t and exp_l >= t), (len(a), len(b), t, int(got[1]), exp_l)
 
 
 def test_device_seed_and_extension_matches_oracle(gpu_pair):
