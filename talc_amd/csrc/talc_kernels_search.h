@@ -471,6 +471,7 @@ struct Wv {
   uint32_t Ls, Le, Rs, Re;         // m_LEFT_KMpositions / m_RIGHT_KMpositions
   uint32_t weakLen;
   bool complexRegion;
+  bool ffPopped;                   // the fast-forward recorded a bridge longer than the reference: its Trail is gone
   int nAncL, nAncR;
   uint32_t refLen;
   int nFull; uint32_t fullUsed;
@@ -1592,6 +1593,9 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     if (edge) maxSteps = min(maxSteps, (int)(CHECK - (sc0 % CHECK)));   // up to and including the next scoring step
   }
   gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
+  const int nAims = edge ? 0 : uni(dirRight ? X.nAncR : X.nAncL);
+  int lanc = uni((int)r0.lanc), ranc = uni((int)r0.ranc);
+  bool popped = false;
   uint32_t* recN = (uint32_t*)g_dp;   // counts of the committed, not yet flushed steps (the DP stage is idle here)
   uint32_t cFlush = cnt;
   double dist = r0.dist;
@@ -1670,21 +1674,52 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     const unsigned long long bm = (1ull << ((hv >> 20) & 63u)) | (1ull << ((hv >> 14) & 63u));
     const unsigned long long bv = g_bloom[bwi];
     const unsigned long long hitMask = ballot64(((bv & bm) == bm) || dup) | (1ull << TALC_WALK_LEVELS);
-    nOK = min(nOK, __builtin_ctzll(hitMask));
-    if (nOK == 0) break;
-    // ---- commit nOK steps
-    if (l < nOK) {
+    const int hitLevel = __builtin_ctzll(hitMask);
+    // a filter hit on a level that could otherwise be taken: if its k-mer is an aim, that step is a plain step that
+    // also records the bridge (oneMoreStep, Explorer.cpp:566-583) — taken here as well; anything else (a possible
+    // cycle, a false positive, aims beyond the LDS copy) is left to the generic step
+    int aimIdx = -1;
+    if (nAims > 0 && nAims <= AIMS_LDS && hitLevel < nOK) {
+      const uint64_t kmH = ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(km >> 32), hitLevel) << 32) | (uint32_t)lane_get((int)(uint32_t)km, hitLevel);
+      const unsigned long long am = ballot64((l < nAims) && (g_aimK[l < AIMS_LDS ? l : 0] == kmH) && (g_aimN[l < AIMS_LDS ? l : 0] == 0ull));
+      if (am != 0ull) aimIdx = (int)__builtin_ctzll(am);   // checkAims takes the first aim that matches (Trail.cpp:273-285)
+    }
+    nOK = min(nOK, hitLevel);
+    const int nTake = nOK + (aimIdx >= 0 ? 1 : 0);
+    if (nTake == 0) break;
+    // ---- commit nTake steps
+    if (l < nTake) {
       atomicOr(&g_bloom[bwi], bm);
       recN[done - flushed + l] = top;
       seq[len0 + done + l] = (uint8_t)which;
     }
-    const int last = nOK - 1;
+    const int last = nTake - 1;
     kmer = ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(km >> 32), last) << 32) | (uint32_t)lane_get((int)(uint32_t)km, last);
     key = dirRight ? (kmer & m1) : (kmer >> 2);
     hh = (uint32_t)lane_get((int)hv, last);
     cnt = (uint32_t)lane_get((int)top, last);
-    done += nOK;
+    done += nTake;
     LSYNC();
+    if (aimIdx >= 0) {
+      // recordBridge (Explorer.cpp:1097-1101) for the Trail as it stands after this step
+      flush();
+      WSYNC();   // the bases the lanes have stored are read back by the copy
+      const int apos = (int)g_aimPos[aimIdx];
+      if (dirRight) ranc = apos; else lanc = apos;
+      const uint32_t clen = (uint32_t)(len0 + done);
+      if (X.nFull >= (int)X.C.fullCap) X.overflow |= OVF_FULLPATHS;
+      else if (X.fullUsed + clen > X.C.fullPool) X.overflow |= OVF_FULLPOOL;
+      else {
+        wave_copy_bytes(X.fullPool + X.fullUsed, (const uint8_t*)seq, clen, false);
+        if (l == 0) X.fullMeta[X.nFull] = FullMeta{X.fullUsed, clen, lanc, ranc, dist / ((double)clen + 0.01)};
+        X.fullUsed += (clen + 15u) & ~15u;
+        X.nFull++;
+        WSYNC();
+      }
+      if (X.overflow) break;
+      if (clen > X.refLen) { popped = true; break; }   // :579-582 pop_back: the Trail ends here
+      continue;                                        // the record was cut at the aim: next record from the new tip
+    }
     if (nOK < TALC_WALK_LEVELS) break;
   }
   flush();
@@ -1696,10 +1731,11 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     X.steps += (unsigned long long)done;
     if (l == 0) {
       TrailRec r = r0;
-      r.kmer = kmer; r.cnt = cnt; r.dist = dist;
+      r.kmer = kmer; r.cnt = cnt; r.dist = dist; r.lanc = lanc; r.ranc = ranc;
       tr_put(X.ia, 0, r);
     }
   }
+  if (popped) { pool_free((int)r0.buf); X.ffPopped = true; }
   LSYNC();
   return done;
 }
@@ -1798,7 +1834,11 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
     int nCur = 1;
     int len = (int)K;
     while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
-      if (nCur == 1) { PROF_BEGIN2(); len += fast_forward(len, stepCounter, PATH_MAXLENGTH, false); PROF_END2(PF_FFWD); if (!(stepCounter < PATH_MAXLENGTH)) break; }
+      if (nCur == 1) {
+        PROF_BEGIN2(); len += fast_forward(len, stepCounter, PATH_MAXLENGTH, false); PROF_END2(PF_FFWD);
+        if (X.ffPopped) { X.ffPopped = false; nCur = 0; break; }   // its last step recorded a bridge and ended the Trail
+        if (!(stepCounter < PATH_MAXLENGTH)) break;
+      }
       PROF_BEGIN2();
       nCur = step_bridge(nCur, len, stepCounter);
       PROF_END2(PF_STEPB);
@@ -2023,7 +2063,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     const uint32_t outCap = (uint32_t)(outoff[r + 1] - outoff[r]);
     ReadState st = state[r];
     X.read = codes + rb; X.L = L; X.n = L >= P.K ? L - P.K + 1 : 0; X.cov = covAll + koff[r]; X.lambda = st.lambda;
-    X.cells = 0; X.steps = 0; X.overflow = 0; X.complexRegion = false;
+    X.cells = 0; X.steps = 0; X.overflow = 0; X.complexRegion = false; X.ffPopped = false;
     X.tracing = (trace.recs != nullptr) && (r == traceRead);
 
     if (st.status != TALC_READ_CORRECTED || st.overflow) {
