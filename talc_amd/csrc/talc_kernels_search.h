@@ -472,8 +472,6 @@ struct Wv {
   uint32_t weakLen;
   bool complexRegion;
   bool ffPopped;                   // the fast-forward recorded a bridge longer than the reference: its Trail is gone
-  // wavefront state handed from one scoring of the edge's single Trail to the next (WfaResume, talc_wave.h)
-  bool snapValid, snapState; int snapLevel, snapBuf, snapRefLen, snapCandLen;
   int nAncL, nAncR;
   uint32_t refLen;
   int nFull; uint32_t fullUsed;
@@ -842,14 +840,10 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 
 // growth-order restatement: the seed sits at the anchor end; extension starts at offset S
 // (K-1 walking RIGHT: Seed(0,0,K-1,K-1); K walking LEFT: Seed(len-K, len-K, len-1, len-1)).
-// resumeBuf >= 0: the candidate is the edge's single Trail in sequence buffer resumeBuf, scored in place every
-// CHECK_INTERVAL steps: the wavefront state is handed from one such call to the next (WfaResume).  Any other call
-// drops the handed-over state.
 TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
-                                  bool withScore, int resumeBuf_ = -1) {
+                                  bool withScore) {
   PROF_DECL;
   refLen = uni(refLen); candLen = uni(candLen); xdrop = uni(xdrop); ref = uni_ptr(ref); cand = uni_ptr(cand);
-  const int resumeBuf = uni(resumeBuf_);
   const int K = (int)X.P.K;
   const int S = X.dirRight ? K - 1 : K;
   SeedExt r;
@@ -861,29 +855,16 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
   int extCols = 0, extRows = 0, extScore = 0, rc = 0;
   unsigned long long ncells = 0;
   const int qlen = len2 - S, dlen = len1 - S;
-  if (!(qlen > 0 && dlen > 0)) X.snapValid = false;
   if (qlen > 0 && dlen > 0) {
     PROF_BEGIN();
     constexpr int STAGE = 3 * LDS_DP_CAP * 4;
     uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
     // furthest-reaching wavefronts, 1 / 2 / 4 diagonals per lane (x up to 31 / 63 / 127)
     const int ndiagonals = min(max(xdrop, 0), qlen) + min(max(xdrop, 0), dlen) + 1;
-    WfaResume rsv;
-    WfaResume* rs = nullptr;
-    if (resumeBuf >= 0 && X.C.dpCap >= 1024u) {
-      int* base = X.dpG + 2ull * X.C.dpCap + 256;   // (past the flags of the multi-x run; 2 x 256 ints)
-      rsv.inF = base; rsv.inE = base + 256; rsv.outF = base; rsv.outE = base + 256; rsv.outLevel = -1;
-      const bool usable = X.snapValid && X.snapBuf == resumeBuf && X.snapState == state && X.snapRefLen == refLen &&
-                          X.snapCandLen <= candLen;
-      rsv.inLevel = usable ? X.snapLevel : -1;
-      rs = &rsv;
-    }
-    if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, rs);
-    else if (ndiagonals <= 127) rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, rs);
-    else if (ndiagonals <= 255) rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, rs);
+    if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (ndiagonals <= 127) rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (ndiagonals <= 255) rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
     else rc = -1;
-    X.snapValid = (rs != nullptr) && (rc >= 0) && (rsv.outLevel >= 0);
-    if (X.snapValid) { X.snapLevel = rsv.outLevel; X.snapBuf = resumeBuf; X.snapState = state; X.snapRefLen = refLen; X.snapCandLen = candLen; }
     if (rc < 0) {   // band wider than a wavefront (x-drop above ~30): anti-diagonals in LDS, or in HBM when too long
       const int need = qlen + 3;
       extCols = extRows = 0; rc = -1;
@@ -976,11 +957,10 @@ TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint
 }
 
 // Trail::seedAndExtend (Trail.cpp:193-216) on slot t of set S; returns `ok`
-TALC_DN bool trail_seed_and_extend(int set, int t, int len, int xdrop, bool resume = false) {
+TALC_DN bool trail_seed_and_extend(int set, int t, int len, int xdrop) {
   WSYNC();   // the Trail's last bases were appended by lane 0: make them visible to the DP lanes
   TrailRec r = tr_get(set, t);
-  const SeedExt e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)r.buf * X.C.seqCap, len, xdrop, true,
-                                       resume ? (int)r.buf : -1);
+  const SeedExt e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)r.buf * X.C.seqCap, len, xdrop, true);
   const bool ok1 = (e.lenHistExt == len);
   r.fail = ok1 ? 0u : r.fail + 1u;
   r.score = e.score;
@@ -1319,7 +1299,7 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
 // Explorer::scoreEdges (Explorer.cpp:709-740) on the new set (n trails of length len); survivors
 // are compacted in place; returns their number
 // (ib = the Trail set to score: the new set of a generic step, or the current set when the fast-forward took the step)
-TALC_DN int score_edges(int ib_, int n, int len, int& xdrop, bool resume = false) {
+TALC_DN int score_edges(int ib_, int n, int len, int& xdrop) {
   if (n == 0) return 0;
   const int l = lane_id();
   const int ib = uni(ib_);
@@ -1328,7 +1308,7 @@ TALC_DN int score_edges(int ib_, int n, int len, int& xdrop, bool resume = false
   int nSel = 0;
   // trash paths are only needed when nobody survives: remember them by flag in gKept
   for (int t = 0; t < n; ++t) {
-    const bool ok = trail_seed_and_extend(ib, t, len, xdrop, resume && n == 1);
+    const bool ok = trail_seed_and_extend(ib, t, len, xdrop);
     if (l == 0) X.gKept[t] = ok ? 1u : 0u;
     if (ok) {
       const int current_xdrop = (int)((double)tr_get(ib, t).score * (-1));
@@ -1778,7 +1758,6 @@ TALC_D void init_first_trail(const AnchorRec& a, bool withAims) {
   const uint32_t b0 = (uint32_t)pool_alloc();
   wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
   g_bloom[lane_id()] = 0ull;
-  X.snapValid = false;   // (sequence buffers are handed out afresh: no wavefront state survives a new search)
   LSYNC();
   if (withAims) {
     const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
@@ -1980,7 +1959,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
           // the fast-forward took the step after which scoring is due (Explorer.cpp:672-686): the one Trail stays
           // where it is (set ia, slot 0) — score it there; five or fewer survivors means no gardening
           PROF_BEGIN2();
-          nCur = score_edges(X.ia, 1, len, xdrop, true);
+          nCur = score_edges(X.ia, 1, len, xdrop);
           PROF_END2(PF_STEPE);
           continue;
         }
@@ -2084,7 +2063,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     const uint32_t outCap = (uint32_t)(outoff[r + 1] - outoff[r]);
     ReadState st = state[r];
     X.read = codes + rb; X.L = L; X.n = L >= P.K ? L - P.K + 1 : 0; X.cov = covAll + koff[r]; X.lambda = st.lambda;
-    X.cells = 0; X.steps = 0; X.overflow = 0; X.complexRegion = false; X.ffPopped = false; X.snapValid = false;
+    X.cells = 0; X.steps = 0; X.overflow = 0; X.complexRegion = false; X.ffPopped = false;
     X.tracing = (trace.recs != nullptr) && (r == traceRead);
 
     if (st.status != TALC_READ_CORRECTED || st.overflow) {

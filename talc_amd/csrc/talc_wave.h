@@ -478,27 +478,14 @@ TALC_D int wfa_select(const int (&F)[NR], const int (&E)[NR], int kmin, int kmax
   return firstMax(A - 1);
 }
 
-// Resuming.  The same Trail is scored again every CHECK_INTERVAL steps, a few bases longer each time.  The state
-// after level e does not depend on how long the two segments are as long as no match run of levels 0..e ended at the
-// end of a (staged) segment — every stop was a base mismatch, which the longer segments leave where it is.  A run
-// therefore hands over the state after the last level before its first such touch (levels below x only: the last
-// level is the one the uninitialised-border rule acts on), stored by diagonal (index k + 128), and the next run of the
-// same Trail — same sequences, segments at least as long, that level still below its x — starts from there instead
-// of from level 0: typically the last two or three levels instead of thirty.
-struct WfaResume {
-  const int* inF; const int* inE; int inLevel;   // state to start from (inLevel < 0: none)
-  int* outF; int* outE; int outLevel;           // state handed over (outLevel < 0: none)
-};
-
 template <int NR>
 TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int x,
                           uint8_t TALC_AS3* stage, int stageCap, int& extCols, int& extRows, int& extScore,
-                          unsigned long long& cells, WfaResume* rs = nullptr) {
+                          unsigned long long& cells) {
   gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
   qlen = uni(qlen); dlen = uni(dlen); x = uni(x);
   extCols = extRows = extScore = 0;
-  if (rs) rs->outLevel = -1;
   if (qlen <= 0 || dlen <= 0) return 0;
   const int NEG = -(1 << 29);
   const int X = min(max(x, 0), 1 << 20);
@@ -545,58 +532,25 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
       }
     }
   };
-  // a segment end met by a match run of lane's diagonal (wave-uniform answer)
-  auto touches = [&](const bool (&mv)[NR]) -> bool {
-    bool t = false;
-#pragma unroll
-    for (int s = 0; s < NR; ++s) {
-      const int k = kmin + 64 * s + l;
-      t |= mv[s] & ((((F[s] + k) >> 1) >= qS) | (((F[s] - k) >> 1) >= dS));
-    }
-    return ballot64(t) != 0ull;
-  };
-  int Fkeep[NR], Ekeep[NR];   // the state to hand over: after level keepLevel, no touch up to there
-  int keepLevel = -1;
-  bool touched = false;
-  int eStart = 1;
-  bool cornerHit = false;
-  int cornerE = 0;
-  if (rs && rs->inLevel >= 0 && rs->inLevel < x && rs->inLevel <= 126) {
-    const int lv = rs->inLevel;
-#pragma unroll
-    for (int s = 0; s < NR; ++s) {
-      const int j = 64 * s + l, k = kmin + j, ak = k < 0 ? -k : k;
-      const bool in = (j < nd) & (ak <= lv);
-      F[s] = in ? rs->inF[in ? k + 128 : 128] : NEG;
-      E[s] = in ? rs->inE[in ? k + 128 : 128] : 0;
-      Fkeep[s] = F[s]; Ekeep[s] = E[s];
-    }
-    keepLevel = lv;
-    eStart = lv + 1;
-  } else {
+  {
     int a0[NR]; bool act0[NR];
     const int j0 = -kmin;
 #pragma unroll
     for (int s = 0; s < NR; ++s) { a0[s] = 0; act0[s] = (64 * s + l == j0) && x >= 0; }
-    bool mv0[NR];
-#pragma unroll
-    for (int s = 0; s < NR; ++s) mv0[s] = act0[s];
     extend(a0, act0);
 #pragma unroll
     for (int s = 0; s < NR; ++s) if (64 * s + l == j0) F[s] = a0[s];
+  }
+  bool cornerHit = false;
+  int cornerE = 0;
+  {
     unsigned long long hit = 0;
 #pragma unroll
     for (int s = 0; s < NR; ++s) hit |= ballot64(F[s] == corner);
     cornerHit = hit != 0ull;
-    touched = touches(mv0);
-    if (!touched && x >= 1) {
-#pragma unroll
-      for (int s = 0; s < NR; ++s) { Fkeep[s] = F[s]; Ekeep[s] = E[s]; }
-      keepLevel = 0;
-    }
   }
   unsigned long long work = 0;
-  for (int e = eStart; e <= x && !cornerHit; ++e) {
+  for (int e = 1; e <= x && !cornerHit; ++e) {
     int rotR[NR], rotL[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) { rotR[s] = lane_ror1(F[s]); rotL[s] = lane_rol1(F[s]); }
@@ -629,24 +583,8 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     }
     work += (unsigned long long)min(nd, 2 * e + 1);
     if (hit != 0ull) { cornerHit = true; cornerE = e; }
-    if (rs && !touched) {
-      if (touches(moved)) touched = true;
-      else if (e < x) {
-#pragma unroll
-        for (int s = 0; s < NR; ++s) { Fkeep[s] = F[s]; Ekeep[s] = E[s]; }
-        keepLevel = e;
-      }
-    }
   }
   cells += work;
-  if (rs && keepLevel >= 0 && keepLevel <= 126) {
-#pragma unroll
-    for (int s = 0; s < NR; ++s) {
-      const int j = 64 * s + l, k = kmin + j, ak = k < 0 ? -k : k;
-      if ((j < nd) & (ak <= keepLevel)) { rs->outF[k + 128] = Fkeep[s]; rs->outE[k + 128] = Ekeep[s]; }
-    }
-    rs->outLevel = keepLevel;
-  }
   if (cornerHit) { extCols = qlen; extRows = dlen; extScore = -cornerE; return 1; }
   return wfa_select<NR>(F, E, kmin, kmax, qlen, dlen, extCols, extRows, extScore);
 }
