@@ -1624,48 +1624,8 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   const int lj = min(l, TALC_WALK_LEVELS - 1);                // shift amounts stay in range on the idle lanes
   uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
   uint32_t hh = (uint32_t)(table_hash(key) >> 32);
-  // A level the record cannot vouch for (two successors reach MIN_COUNT, a count beyond 16 bits): the tip's bucket
-  // and the count model (tagNextNodes, Explorer.cpp:1230-1290) decide as in the generic step; if exactly ONE successor
-  // becomes a Trail (the usual outcome next to an erroneous k-mer) that step is an ordinary one and is taken here.
-  auto model_step = [&]() -> bool {
-    const Bucket TALC_AS4* tab = (const Bucket TALC_AS4*)uni_ptr(dirRight ? X.T.right : X.T.left);
-    uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
-    v8u32 b = *(const v8u32 TALC_AS4*)(tab + slot);
-    while (true) {
-      const uint64_t bk = ((uint64_t)b[1] << 32) | b[0];
-      if (bk == key) break;
-      if (bk == kEmptyKey) return false;
-      if (++slot == cap) slot = 0;
-      b = *(const v8u32 TALC_AS4*)(tab + slot);
-    }
-    const uint32_t c4[4] = {b[2], b[3], b[4], b[5]};
-    const uint32_t j4[4] = {b[6] & 0xffffu, b[6] >> 16, b[7] & 0xffffu, b[7] >> 16};
-    int tags[4]; double ds[4];
-    if (tag_next_nodes(P.ALPHA, P.ERR, MINC, c4, j4, cnt, false, tags, ds) == 0) return false;
-    int nch = 0, bsel = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (tags[i] != TAG_NONE && tags[i] != TAG_UNEXPECTED) { ++nch; bsel = i; }
-    if (nch != 1) return false;
-    uint32_t csel = c4[0];
-#pragma unroll
-    for (int i = 1; i < 4; ++i) if (i == bsel) csel = c4[i];
-    uint64_t km2;
-    if (dirRight) km2 = ((kmer << 2) | (uint64_t)bsel) & kmask;
-    else km2 = ((uint64_t)bsel << (2 * (K - 1))) | (kmer >> 2);
-    const uint64_t key2 = dirRight ? (km2 & m1) : (km2 >> 2);
-    const uint32_t h2 = (uint32_t)(table_hash(key2) >> 32);
-    const int bwi = (int)(h2 >> 26);
-    const unsigned long long bm = (1ull << ((h2 >> 20) & 63u)) | (1ull << ((h2 >> 14) & 63u));
-    const unsigned long long bv = g_bloom[bwi];
-    if ((bv & bm) == bm) return false;   // an aim, a possible cycle: the generic step
-    if (l == 0) { g_bloom[bwi] = bv | bm; recN[done - flushed] = csel; seq[len0 + done] = (uint8_t)bsel; }
-    kmer = km2; key = key2; hh = h2; cnt = csel;
-    ++done;
-    LSYNC();
-    return true;
-  };
   while (done < maxSteps) {
-    if (done - flushed > 64 - TALC_WALK_LEVELS - 1) flush();   // room for a record's steps and one model step
+    if (done - flushed > 64 - TALC_WALK_LEVELS) flush();
     uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
     uint32_t e = wtab[slot * 16 + laneOff];
     bool found = true;
@@ -1680,12 +1640,8 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     const uint32_t top = e & 0xFFFFu, next = (e >> 16) & kWalkNextMask;
     // levels that are "exactly one successor with count >= MIN_COUNT", from level 0 up to the first that is not
     const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && top != kWalkTopNone && top >= MINC && next < MINC);
-    const int nPass = __builtin_ctzll(~passMask);
-    int nOK = min(nPass, maxSteps - done);
-    if (nOK == 0) {
-      if (nPass == 0 && model_step()) continue;   // (nOK == 0 with nPass > 0 cannot happen: done < maxSteps here)
-      break;
-    }
+    int nOK = min(__builtin_ctzll(~passMask), maxSteps - done);
+    if (nOK == 0) break;
     // lane j's tip after its step: the current tip shifted by j+1 bases, with the bases of levels 0..j
     const uint32_t which = (l < TALC_WALK_LEVELS) ? (e >> 30) : 0u;
     uint32_t pre = which << (dirRight ? 2 * (TALC_WALK_LEVELS - 1 - lj) : 2 * lj);
@@ -1764,11 +1720,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
       if (clen > X.refLen) { popped = true; break; }   // :579-582 pop_back: the Trail ends here
       continue;                                        // the record was cut at the aim: next record from the new tip
     }
-    if (nOK < TALC_WALK_LEVELS) {
-      // stopped by the level after the committed ones, with nothing else in the way: the model may take it
-      if (nOK == nPass && hitLevel > nPass && done < maxSteps && model_step()) continue;
-      break;
-    }
+    if (nOK < TALC_WALK_LEVELS) break;
   }
   flush();
   stepCounter_ = sc0 + (uint32_t)done;
