@@ -862,6 +862,20 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
     // furthest-reaching wavefronts, 1 / 2 / 4 diagonals per lane (x up to 31 / 63 / 127)
     const int ndiagonals = min(max(xdrop, 0), qlen) + min(max(xdrop, 0), dlen) + 1;
     if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (ndiagonals <= 255 && X.C.dpCap >= 1024u) {
+      // in phases (WfaPhase): levels 0..31 one diagonal per lane, 32..63 two, the rest four
+      int* mem = X.dpG + 2ull * X.C.dpCap + 256;   // (past the flags of the multi-x run)
+      WfaPhase ph{-1, 31, mem, mem + 256};
+      rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+      if (rc == 2) {
+        ph.fromLevel = 31; ph.toLevel = (ndiagonals <= 127) ? -1 : 63;
+        rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+        if (rc == 2) {
+          ph.fromLevel = 63; ph.toLevel = -1;
+          rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+        }
+      }
+    }
     else if (ndiagonals <= 127) rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
     else if (ndiagonals <= 255) rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
     else rc = -1;

@@ -478,10 +478,21 @@ TALC_D int wfa_select(const int (&F)[NR], const int (&E)[NR], int kmin, int kmax
   return firstMax(A - 1);
 }
 
+// Phases.  Level e only involves the diagonals |k| <= e, so a run whose x needs 2 or 4 diagonals per lane can take its
+// first 31 levels with one diagonal per lane, the next 32 with two, and only the rest at full width: a phase stops
+// after level `toLevel`, leaves the state in memory by diagonal (index k + 128), and the next, wider instance
+// continues from there (`fromLevel`).  The segments are staged once, by the first phase, for the run's real x.
+// Return value 2 = "to be continued"; a phase that reaches the far corner ends the whole run (return 1).
+struct WfaPhase {
+  int fromLevel;        // -1: first phase (stages the segments, takes level 0)
+  int toLevel;          // -1: last phase (runs to level x and selects)
+  int* memF; int* memE;
+};
+
 template <int NR>
 TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int x,
                           uint8_t TALC_AS3* stage, int stageCap, int& extCols, int& extRows, int& extScore,
-                          unsigned long long& cells) {
+                          unsigned long long& cells, const WfaPhase* ph = nullptr) {
   gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
   qlen = uni(qlen); dlen = uni(dlen); x = uni(x);
@@ -489,16 +500,20 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   if (qlen <= 0 || dlen <= 0) return 0;
   const int NEG = -(1 << 29);
   const int X = min(max(x, 0), 1 << 20);
-  const int kmin = -min(X, dlen), kmax = min(X, qlen);
+  const int fromLevel = ph ? ph->fromLevel : -1, toLevel = ph ? ph->toLevel : -1;
+  const int Xm = (toLevel >= 0) ? min(X, toLevel) : X;   // the diagonals this phase can meet
+  const int kmin = -min(Xm, dlen), kmax = min(Xm, qlen);
   const int nd = kmax - kmin + 1;
   if (nd > 64 * NR - 1) return -1;   // one always-empty lane closes the ring of the lane rotations
   // only cells with |col - row| <= x can be kept: stage that much of each segment, then a sentinel
   const int qS = min(qlen, dlen + X), dS = min(dlen, qlen + X);
   const int qpad = (qS + 16) & ~7;
   if (qpad + dS + 16 > stageCap) return -1;
-  for (int i = l; i < qS; i += 64) stage[i] = querySeg[i];
-  for (int i = l; i < dS; i += 64) stage[qpad + i] = dbSeg[i];
-  if (l == 0) { stage[qS] = 0xF0; stage[qpad + dS] = 0xF1; }   // differ from each other and from every base code
+  if (fromLevel < 0) {
+    for (int i = l; i < qS; i += 64) stage[i] = querySeg[i];
+    for (int i = l; i < dS; i += 64) stage[qpad + i] = dbSeg[i];
+    if (l == 0) { stage[qS] = 0xF0; stage[qpad + dS] = 0xF1; }   // differ from each other and from every base code
+  }
   WSYNC();
   const int bmax = x >= 2 ? x - 1 : (x == 1 ? 1 : 0);
   const int corner = qlen + dlen;
@@ -532,7 +547,19 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
       }
     }
   };
-  {
+  bool cornerHit = false;
+  int cornerE = 0;
+  int eStart = 1;
+  if (fromLevel >= 0) {   // the state the narrower phase left behind
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int j = 64 * s + l, k = kmin + j, ak = k < 0 ? -k : k;
+      const bool in = (j < nd) & (ak <= fromLevel);
+      F[s] = in ? ph->memF[in ? k + 128 : 128] : NEG;
+      E[s] = in ? ph->memE[in ? k + 128 : 128] : 0;
+    }
+    eStart = fromLevel + 1;
+  } else {
     int a0[NR]; bool act0[NR];
     const int j0 = -kmin;
 #pragma unroll
@@ -540,17 +567,14 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     extend(a0, act0);
 #pragma unroll
     for (int s = 0; s < NR; ++s) if (64 * s + l == j0) F[s] = a0[s];
-  }
-  bool cornerHit = false;
-  int cornerE = 0;
-  {
     unsigned long long hit = 0;
 #pragma unroll
     for (int s = 0; s < NR; ++s) hit |= ballot64(F[s] == corner);
     cornerHit = hit != 0ull;
   }
+  const int eEnd = (toLevel >= 0) ? min(x, toLevel) : x;
   unsigned long long work = 0;
-  for (int e = 1; e <= x && !cornerHit; ++e) {
+  for (int e = eStart; e <= eEnd && !cornerHit; ++e) {
     int rotR[NR], rotL[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) { rotR[s] = lane_ror1(F[s]); rotL[s] = lane_rol1(F[s]); }
@@ -586,6 +610,15 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   }
   cells += work;
   if (cornerHit) { extCols = qlen; extRows = dlen; extScore = -cornerE; return 1; }
+  if (toLevel >= 0 && toLevel < x) {   // hand over to the wider instance
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int j = 64 * s + l, k = kmin + j, ak = k < 0 ? -k : k;
+      if ((j < nd) & (ak <= toLevel)) { ph->memF[k + 128] = F[s]; ph->memE[k + 128] = E[s]; }
+    }
+    WSYNC();
+    return 2;
+  }
   return wfa_select<NR>(F, E, kmin, kmax, qlen, dlen, extCols, extRows, extScore);
 }
 
