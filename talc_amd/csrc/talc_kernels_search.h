@@ -1777,9 +1777,10 @@ TALC_D void init_first_trail(const AnchorRec& a, bool withAims) {
     const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
     const int nAims = X.dirRight ? X.nAncR : X.nAncL;
     for (int ai = lane_id(); ai < nAims; ai += 64) {
-      const AnchorRec t = aims[ai];
-      if (t.nmask != 0ull) continue;   // a fast-forwarded tip never holds an N
-      const uint64_t h = bloom_hash(t.kmer, 0ull);
+      // (the first AIMS_LDS aims are in LDS already, search_bridge put them there)
+      const uint64_t tk = ai < AIMS_LDS ? g_aimK[ai] : aims[ai].kmer, tn = ai < AIMS_LDS ? g_aimN[ai] : aims[ai].nmask;
+      if (tn != 0ull) continue;   // a fast-forwarded tip never holds an N
+      const uint64_t h = bloom_hash(tk, 0ull);
       atomicOr(&g_bloom[bloom_word(h)], bloom_mask(h));
     }
     LSYNC();
