@@ -1622,12 +1622,13 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     const uint32_t cn = (l < n) ? recN[l] : 1u;
     const uint32_t cprev = (l == 0) ? cFlush : ((l < n) ? recN[l - 1] : 1u);
     const double term = fabs((double)cprev - (double)cn) / sqrt((double)cprev);
-    const unsigned long long tb = (unsigned long long)__double_as_longlong(term);
-    const int tLo = (int)(uint32_t)tb, tHi = (int)(uint32_t)(tb >> 32);
-    for (int j = 0; j < n; ++j) {
-      const unsigned long long v = ((unsigned long long)(uint32_t)lane_get(tHi, j) << 32) | (uint32_t)lane_get(tLo, j);
-      dist = dist + __longlong_as_double((long long)v);
-    }
+    // added in path order (the same double additions as step by step): the terms go through LDS, whose reads the
+    // compiler can issue several at a time ahead of the dependent additions
+    double* recT = (double*)(g_dp + 64);
+    recT[l] = term;
+    LSYNC();
+#pragma unroll 8
+    for (int j = 0; j < n; ++j) dist = dist + recT[j];
     cFlush = (uint32_t)lane_get((int)cn, n - 1);
     flushed = done;
     LSYNC();
