@@ -1576,9 +1576,9 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
 // together, one level per lane: lane j < 14 loads level j (lanes 14, 15 the key), the lanes test "exactly one successor"
 // and build their k-mers from the prefix of the levels' bases, hash them, query the search's filter (LDS) — a
 // ballot gives the number of steps that can be committed, and those lanes insert their k-mers, store their bases
-// and record their counts.  One dependent memory access and ~100 instructions per record instead of per step.
+// and record their counts.  One dependent memory access and ~130 instructions per record instead of per step.
 // A k-mer that repeats WITHIN a record (a cycle of period <= 13) would not be seen by a query that precedes the
-// record's inserts: the inserts are atomic ORs that return the word as it was, which shows it (see the loop).
+// record's inserts: lanes compare their hashes with the lower lanes' (equal hash = possible cycle = stop there).
 template <int P>
 TALC_D uint32_t dpp_row_shr(uint32_t v, uint32_t old) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x110 + P, 0xF, 0xF, false);
@@ -1669,12 +1669,26 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     else km = ((uint64_t)pre << (2 * (K - 1 - (uint32_t)lj))) | (kmer >> (2 * (lj + 1)));
     const uint64_t key2 = dirRight ? (km & m1) : (km >> 2);
     const uint32_t hv = (uint32_t)(table_hash(key2) >> 32);   // the filter hash of the new tip = the hash of its probe
+    // possible cycle inside the record: the same hash on a lower lane
+    bool dup = dpp_row_shr<1>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<2>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<3>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<4>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<5>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<6>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<7>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<8>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<9>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<10>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<11>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<12>(hv, ~hv) == hv;
+    dup |= dpp_row_shr<13>(hv, ~hv) == hv;
     static_assert(TALC_WALK_LEVELS == 14, "the lane roles above are written for 14 levels in a 16-lane row");
     // aim / cycle query against the search's filter (init_first_trail entered the aims)
     const int bwi = (int)(hv >> 26);
     const unsigned long long bm = (1ull << ((hv >> 20) & 63u)) | (1ull << ((hv >> 14) & 63u));
     const unsigned long long bv = g_bloom[bwi];
-    const unsigned long long hitMask = ballot64((bv & bm) == bm) | (1ull << TALC_WALK_LEVELS);
+    const unsigned long long hitMask = ballot64(((bv & bm) == bm) || dup) | (1ull << TALC_WALK_LEVELS);
     const int hitLevel = __builtin_ctzll(hitMask);
     // a filter hit on a level that could otherwise be taken: if its k-mer is an aim, that step is a plain step that
     // also records the bridge (oneMoreStep, Explorer.cpp:566-583) — taken here as well; anything else (a possible
@@ -1686,25 +1700,11 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
       if (am != 0ull) aimIdx = (int)__builtin_ctzll(am);   // checkAims takes the first aim that matches (Trail.cpp:273-285)
     }
     nOK = min(nOK, hitLevel);
-    int nTake = nOK + (aimIdx >= 0 ? 1 : 0);
+    const int nTake = nOK + (aimIdx >= 0 ? 1 : 0);
     if (nTake == 0) break;
-    // ---- insert the k-mers of these steps.  The query above preceded the record's own inserts, so a k-mer that
-    // repeats INSIDE the record (a cycle of period <= 13) was not seen by it: the insert returns the word as it was,
-    // and whichever of two equal k-mers is inserted second finds its bits set.  Stop before the first such level
-    // (also when other levels' bits merely add up to it): the generic step decides, as for any filter hit.
-    {
-      unsigned long long old = 0ull;
-      if (l < nTake) old = atomicOr(&g_bloom[bwi], bm);
-      const unsigned long long dupMask = ballot64((l < nTake) && ((old & bm) == bm));
-      if (dupMask != 0ull) {
-        nTake = (int)__builtin_ctzll(dupMask);
-        if (aimIdx >= 0 && hitLevel >= nTake) aimIdx = -1;
-        nOK = min(nOK, nTake);
-        if (nTake == 0) break;
-      }
-    }
     // ---- commit nTake steps
     if (l < nTake) {
+      atomicOr(&g_bloom[bwi], bm);
       recN[done - flushed + l] = top;
       seq[len0 + done + l] = (uint8_t)which;
     }
