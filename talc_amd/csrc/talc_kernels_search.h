@@ -439,7 +439,7 @@ __shared__ TrailRec g_hot[2 * HOT];                 // metadata of the first HOT
 __shared__ uint64_t g_aimK[AIMS_LDS], g_aimN[AIMS_LDS];
 __shared__ uint32_t g_aimPos[AIMS_LDS];             // first AIMS_LDS target anchors
 __shared__ unsigned long long g_bloom[64];          // 4096-bit k-mer Bloom filter of the current search
-__shared__ int g_dp[3 * LDS_DP_CAP];                // x-drop stage / short DP arrays
+__shared__ __attribute__((aligned(16))) int g_dp[3 * LDS_DP_CAP];                // x-drop stage / short DP arrays
 
 struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online (findBestBORDER is a fold)
   bool have; double score; double dist; double idscore; uint32_t len; uint32_t lanc, ranc;
@@ -566,8 +566,8 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
     uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
     const int l = lane_id();
     gcu8 ga = (gcu8)a; gcu8 gb = (gcu8)b;
-    for (int i = l; i < la; i += 64) stage[i] = ga[i];
-    for (int i = l; i < lb; i += 64) stage[qpad + i] = gb[i];
+    stage_copy(stage, ga, la);
+    stage_copy(stage + qpad, gb, lb);
     if (l == 0) { stage[la] = 0xF0; stage[qpad + lb] = 0xF1; }
     WSYNC();
     unsigned long long ncells = 0;

@@ -478,6 +478,17 @@ TALC_D int wfa_select(const int (&F)[NR], const int (&E)[NR], int kmin, int kmax
   return firstMax(A - 1);
 }
 
+// dst[0..n) (LDS, 8-byte aligned) = src[0..n) (global, any alignment): 8 bytes per lane per pass — whole words only, so
+// nothing beyond src[n) is read; the last n % 8 bytes go one by one
+TALC_D void stage_copy(uint8_t TALC_AS3* dst, gcu8 src, int n) {
+  const int l = lane_id();
+  typedef uint64_t __attribute__((aligned(1))) u64u;
+  const int nw = n >> 3;
+  for (int w = l; w < nw; w += 64) ((uint64_t TALC_AS3*)dst)[w] = *(const u64u TALC_AS1*)(src + 8 * w);
+  const int t = (nw << 3) + l;
+  if (t < n) dst[t] = src[t];
+}
+
 // Phases.  Level e only involves the diagonals |k| <= e, so a run whose x needs 2 or 4 diagonals per lane can take its
 // first 31 levels with one diagonal per lane, the next 32 with two, and only the rest at full width: a phase stops
 // after level `toLevel`, leaves the state in memory by diagonal (index k + 128), and the next, wider instance
@@ -510,8 +521,8 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   const int qpad = (qS + 16) & ~7;
   if (qpad + dS + 16 > stageCap) return -1;
   if (fromLevel < 0) {
-    for (int i = l; i < qS; i += 64) stage[i] = querySeg[i];
-    for (int i = l; i < dS; i += 64) stage[qpad + i] = dbSeg[i];
+    stage_copy(stage, querySeg, qS);
+    stage_copy(stage + qpad, dbSeg, dS);
     if (l == 0) { stage[qS] = 0xF0; stage[qpad + dS] = 0xF1; }   // differ from each other and from every base code
   }
   WSYNC();
@@ -645,8 +656,8 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
   const int qS = min(qlen, dlen + X), dS = min(dlen, qlen + X);
   const int qpad = (qS + 16) & ~7;
   if (qpad + dS + 16 > stageCap) return -1;
-  for (int i = l; i < qS; i += 64) stage[i] = querySeg[i];
-  for (int i = l; i < dS; i += 64) stage[qpad + i] = dbSeg[i];
+  stage_copy(stage, querySeg, qS);
+  stage_copy(stage + qpad, dbSeg, dS);
   if (l == 0) { stage[qS] = 0xF0; stage[qpad + dS] = 0xF1; }
   WSYNC();
   const int corner = qlen + dlen;
