@@ -68,15 +68,12 @@ static const int kCovDegRShift = 16, kCovDegLShift = 19;
 // top >= MIN_COUNT > next, that successor is the stored base and its count is top — exact for any MIN_COUNT in
 // [1, 2^14); a level whose bucket does not exist is all zero (no step passes it).  Whatever a record cannot express
 // (a count beyond 16 bits, MIN_COUNT beyond 14) is left to the per-step form / the generic step: never wrong, only slower.
-#define TALC_WALK_LEVELS 13
+#define TALC_WALK_LEVELS 14
 struct __attribute__((aligned(64))) WalkEntry {
   uint64_t key;                      // the bucket's key (kEmptyKey if unused)
   uint32_t lvl[TALC_WALK_LEVELS];    // top | next << 16 | base << 30 per level
-  uint32_t jump;                     // slot of the record WALK_LEVELS steps further along the same chain (kWalkNoJump: none):
-                                     // known as soon as this record arrives, so that record is requested right away
 };
 static_assert(sizeof(WalkEntry) == 64, "walk entry must be 64 bytes");
-static const uint32_t kWalkNoJump = 0xFFFFFFFFu;
 static const uint32_t kWalkTopNone = 0xFFFFu;
 static const uint32_t kWalkNextMask = 0x3FFFu;
 

@@ -123,7 +123,6 @@ __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __r
   BucketRegs r = load_bucket(tab + s);
   const uint64_t key0 = r.key;
   uint32_t lv[TALC_WALK_LEVELS];
-  uint32_t jump = kWalkNoJump;
 #pragma unroll
   for (int i = 0; i < TALC_WALK_LEVELS; ++i) lv[i] = 0;
   if (key0 != kEmptyKey) {
@@ -133,11 +132,10 @@ __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __r
       uint32_t top;
       const uint32_t w = walk_level(r.cnt, top);
       lv[lev] = w;
-      if (top == 0 || top >= kWalkTopNone) break;   // nothing usable beyond this level
+      if (top == 0 || top >= kWalkTopNone || lev == TALC_WALK_LEVELS - 1) break;   // nothing usable beyond this level
       const uint64_t am = w >> 30;
       // successor key: RIGHT appends the base to the (K-1)-mer and drops its first base, LEFT prepends and drops the last
       key = dirRight ? (((key << 2) | am) & m1) : ((am << (2 * (K - 2))) | (key >> 2));
-      if (lev == TALC_WALK_LEVELS - 1) { jump = probe_slot(tab, cap, key); break; }   // where the chain's next record is
       if (!probe_bucket(tab, cap, key, r)) break;   // no such bucket: the remaining levels stay zero
     }
   }
@@ -145,7 +143,7 @@ __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __r
   out[0] = v4u32{(uint32_t)key0, (uint32_t)(key0 >> 32), lv[0], lv[1]};
   out[1] = v4u32{lv[2], lv[3], lv[4], lv[5]};
   out[2] = v4u32{lv[6], lv[7], lv[8], lv[9]};
-  out[3] = v4u32{lv[10], lv[11], lv[12], jump};
+  out[3] = v4u32{lv[10], lv[11], lv[12], lv[13]};
 }
 
 }  // namespace talc

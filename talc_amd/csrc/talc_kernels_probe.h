@@ -37,18 +37,6 @@ TALC_D bool probe_bucket(const Bucket* tab, uint64_t cap, uint64_t key, BucketRe
   }
 }
 
-// the slot of a key (kNoSlot32 if absent)
-static const uint32_t kNoSlot32 = 0xFFFFFFFFu;
-TALC_D uint32_t probe_slot(const Bucket* tab, uint64_t cap, uint64_t key) {
-  uint64_t i = dev_home(key, cap);
-  while (true) {
-    const uint64_t k = ((const uint64_t TALC_AS1*)(tab + i))[0];
-    if (k == key) return (uint32_t)i;
-    if (k == kEmptyKey) return kNoSlot32;
-    if (++i == cap) i = 0;
-  }
-}
-
 // getCount (Jellyfish.cpp:407-413) for a packed K-mer
 TALC_D void dev_get_count(const TableView& T, uint64_t kmer, uint32_t& cnt, uint32_t& jc) {
   BucketRegs r;

@@ -1577,7 +1577,7 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
 // and build their k-mers from the prefix of the levels' bases, hash them, query the search's filter (LDS) — a
 // ballot gives the number of steps that can be committed, and those lanes insert their k-mers, store their bases
 // and record their counts.  One dependent memory access and ~130 instructions per record instead of per step.
-// A k-mer that repeats WITHIN a record (a cycle of period <= 12) would not be seen by a query that precedes the
+// A k-mer that repeats WITHIN a record (a cycle of period <= 13) would not be seen by a query that precedes the
 // record's inserts: lanes compare their hashes with the lower lanes' (equal hash = possible cycle = stop there).
 template <int P>
 TALC_D uint32_t dpp_row_shr(uint32_t v, uint32_t old) {
@@ -1634,49 +1634,24 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     LSYNC();
   };
 
-  // lane j < 13 reads level j, lane 13 the jump slot, lanes 14 / 15 the two halves of the key (the lanes above repeat lane 14)
-  const uint32_t laneOff = (l < TALC_WALK_LEVELS) ? (uint32_t)(2 + l) : (l == 13 ? 15u : (l == 15 ? 1u : 0u));
+  // lane j < 14 reads level j, lanes 14 / 15 the two halves of the key (the lanes above them repeat lane 14)
+  const uint32_t laneOff = (l < TALC_WALK_LEVELS) ? (uint32_t)(2 + l) : (l == TALC_WALK_LEVELS + 1 ? 1u : 0u);
   const int lj = min(l, TALC_WALK_LEVELS - 1);                // shift amounts stay in range on the idle lanes
   uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
   uint32_t hh = (uint32_t)(table_hash(key) >> 32);
-  // The record 13 steps further along the chain is requested the moment the current record arrives (its slot is in
-  // the record: `jump`), so its latency runs under the current record's work instead of after it.  That load is an
-  // inline-asm instruction: the compiler would sink an ordinary load to its only use, the next iteration; it does
-  // not count the load in its own s_waitcnt bookkeeping (which only makes its waits conservative), so the one
-  // explicit wait sits in the same asm statement as the first read of the destination register, and every way out
-  // of the loop waits before the register can be reused.
-  uint32_t eAhead = 0;        // the requested record (this lane's dword), valid iff haveAhead
-  bool haveAhead = false;
-  uint32_t slotAhead = 0;
   while (done < maxSteps) {
     if (done - flushed > 64 - TALC_WALK_LEVELS) flush();
-    uint64_t slot;
-    uint32_t e;
-    if (haveAhead) {
-      slot = slotAhead;
-      asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %1" : "=&v"(e) : "v"(eAhead) : "memory");
-      haveAhead = false;
-    } else {
-      slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
-      e = wtab[slot * 16 + laneOff];
-    }
+    uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
+    uint32_t e = wtab[slot * 16 + laneOff];
     bool found = true;
     while (true) {   // linear probing, as in the bucket table (same slots)
-      const uint64_t bk = ((uint64_t)(uint32_t)lane_get((int)e, 15) << 32) | (uint32_t)lane_get((int)e, 14);
+      const uint64_t bk = ((uint64_t)(uint32_t)lane_get((int)e, TALC_WALK_LEVELS + 1) << 32) | (uint32_t)lane_get((int)e, TALC_WALK_LEVELS);
       if (bk == key) break;
       if (bk == kEmptyKey) { found = false; break; }
       if (++slot == cap) slot = 0;
       e = wtab[slot * 16 + laneOff];
     }
     if (!found) break;
-    {
-      const uint32_t jump = (uint32_t)lane_get((int)e, 13);
-      if (jump != kWalkNoJump && maxSteps - done > TALC_WALK_LEVELS) {
-        slotAhead = jump;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(eAhead) : "v"(wtab + (uint64_t)jump * 16 + laneOff) : "memory");
-        haveAhead = true;
-      }
-    }
     const uint32_t top = e & 0xFFFFu, next = (e >> 16) & kWalkNextMask;
     // levels that are "exactly one successor with count >= MIN_COUNT", from level 0 up to the first that is not
     const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && top != kWalkTopNone && top >= MINC && next < MINC);
@@ -1707,7 +1682,8 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     dup |= dpp_row_shr<10>(hv, ~hv) == hv;
     dup |= dpp_row_shr<11>(hv, ~hv) == hv;
     dup |= dpp_row_shr<12>(hv, ~hv) == hv;
-    static_assert(TALC_WALK_LEVELS == 13, "the lane roles above are written for 13 levels in a 16-lane row");
+    dup |= dpp_row_shr<13>(hv, ~hv) == hv;
+    static_assert(TALC_WALK_LEVELS == 14, "the lane roles above are written for 14 levels in a 16-lane row");
     // aim / cycle query against the search's filter (init_first_trail entered the aims)
     const int bwi = (int)(hv >> 26);
     const unsigned long long bm = (1ull << ((hv >> 20) & 63u)) | (1ull << ((hv >> 14) & 63u));
@@ -1757,15 +1733,10 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
       }
       if (X.overflow) break;
       if (clen > X.refLen) { popped = true; break; }   // :579-582 pop_back: the Trail ends here
-      if (nTake < TALC_WALK_LEVELS && haveAhead) {        // the record was cut at the aim: next record from the new tip
-        asm volatile("s_waitcnt vmcnt(0)" :: "v"(eAhead) : "memory");   // (the abandoned request has landed)
-        haveAhead = false;
-      }
-      continue;
+      continue;                                        // the record was cut at the aim: next record from the new tip
     }
     if (nOK < TALC_WALK_LEVELS) break;
   }
-  asm volatile("s_waitcnt vmcnt(0)" :: "v"(eAhead) : "memory");   // a record requested ahead may still be on its way to its register
   flush();
   stepCounter_ = sc0 + (uint32_t)done;
 #ifdef TALC_PROF
