@@ -945,11 +945,10 @@ TALC_D SeedExt seedext_plain(int refLen, int candLen, int extCols, int extRows, 
 // the extensions of getSeedAndExtension for every x-drop in [0, xHi] from one wavefront run (wave_xdrop_wfa_multi):
 // resCols[x], resRows[x] as wave_xdrop_wfa(x) would report them.  false = not available (ask x by x).
 TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xHi, int* resCols,
-                                      int* resRows, int xLo_ = 0) {
+                                      int* resRows) {
   PROF_DECL;
   refLen = uni(refLen); candLen = uni(candLen); xHi = uni(xHi); ref = uni_ptr(ref); cand = uni_ptr(cand);
   resCols = (int*)uni_ptr(resCols); resRows = (int*)uni_ptr(resRows);
-  const int xLo = uni(xLo_);
   const int K = (int)X.P.K;
   const int S = X.dirRight ? K - 1 : K;
   const bool state = !(refLen < candLen);
@@ -963,8 +962,8 @@ TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint
   unsigned long long ncells = 0;
   const int ndiagonals = min(xHi, qlen) + min(xHi, dlen) + 1;
   int rc = -1;
-  if (ndiagonals <= 63) rc = wave_xdrop_wfa_multi<1>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells, xLo);
-  else if (ndiagonals <= 127) rc = wave_xdrop_wfa_multi<2>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells, xLo);
+  if (ndiagonals <= 63) rc = wave_xdrop_wfa_multi<1>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells);
+  else if (ndiagonals <= 127) rc = wave_xdrop_wfa_multi<2>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells);
   PROF_END(PF_XDROP);
   X.cells += ncells;
   WSYNC();   // lane 0's results are read by every lane
@@ -1014,14 +1013,9 @@ TALC_DN void record_edge(int set, int t, int len0) {
   int* const resCols = X.dpG;
   int* const resRows = X.dpG + X.C.dpCap;
   bool multi = false;
-  if (xdrop1 >= 1 && (uint32_t)(xdrop1 + 1) <= X.C.dpCap)
-    multi = seed_and_extension_multi(A, lenA, Bq, lenB, xdrop1, resCols, resRows, max(0, xdrop1 - 12));
+  if (xdrop1 >= 1 && (uint32_t)(xdrop1 + 1) <= X.C.dpCap) multi = seed_and_extension_multi(A, lenA, Bq, lenB, xdrop1, resCols, resRows);
   auto ext_at = [&](int x) -> SeedExt {
-    if (multi && x >= 0) {
-      const int c = uni(resCols[x]);
-      if (c >= 0) return seedext_plain(lenA, lenB, c, uni(resRows[x]), x);
-      multi = false;   // below what the run selected: from here on x by x (the run's states are gone)
-    }
+    if (multi && x >= 0) return seedext_plain(lenA, lenB, uni(resCols[x]), uni(resRows[x]), x);
     return seed_and_extension(A, lenA, Bq, lenB, x, false);
   };
   nxt = ext_at(xdrop1);

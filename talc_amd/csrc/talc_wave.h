@@ -643,8 +643,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 // Returns -1 when the band does not fit (the caller then asks x by x).
 template <int NR>
 TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int xHi,
-                                uint8_t TALC_AS3* stage, int stageCap, int* resCols, int* resRows, unsigned long long& cells,
-                                int xLo = 0) {
+                                uint8_t TALC_AS3* stage, int stageCap, int* resCols, int* resRows, unsigned long long& cells) {
   gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
   qlen = uni(qlen); dlen = uni(dlen); xHi = uni(xHi);
@@ -700,10 +699,7 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
   auto emit_corner_from = [&](int xFrom) {   // every x >= xFrom reaches the far corner
     for (int x = xFrom + l; x <= xHi; x += 64) { resCols[x] = qlen; resRows[x] = dlen; }
   };
-  // (the selection costs more than a level and the caller reads from xHi downwards, rarely far: below xLo the entry
-  //  is only marked "not selected" (-1) and the caller asks that x by itself)
   auto emit_selected = [&](int x, const int (&f)[NR], const int (&lev)[NR]) {
-    if (x < xLo) { if (l == 0) { resCols[x] = -1; resRows[x] = -1; } return; }
     int c = 0, r = 0, sc = 0;
     if (!wfa_select<NR>(f, lev, kmin, kmax, qlen, dlen, c, r, sc)) { c = 0; r = 0; }
     if (l == 0) { resCols[x] = c; resRows[x] = r; }
