@@ -146,67 +146,46 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   const uint64_t kmaskLE = (K >= 32) ? ~0ULL : ((1ULL << kbits) - 1);
   int local_in = 0;
   uint2* out = cov + koff[r] + p0;
-  // Positions are taken four at a time per thread: the four filter words are requested before the first one is
-  // looked at (four independent random requests in flight per lane instead of one after the other), then each
-  // position goes on as before.
-  constexpr int GRP = 4;
-  for (uint32_t p0g = threadIdx.x; p0g < cnt; p0g += GRP * COV_THREADS) {
-    uint64_t kmers[GRP], fword[GRP], fmask[GRP];
-    bool maybeG[GRP];
-#pragma unroll
-    for (int g = 0; g < GRP; ++g) {
-      const uint32_t p = p0g + (uint32_t)g * COV_THREADS;
-      const bool valid = p < cnt;
-      const uint32_t pp = valid ? p : 0u;
-      // little-endian packed window: base i at bits [2i,2i+1] of the bit stream
-      const uint32_t bit = 2 * pp;
-      const uint32_t w = bit >> 6, sh = bit & 63;
-      uint64_t lo = s_pack[w], hi = s_pack[w + 1];
-      uint64_t le = (sh == 0) ? lo : ((lo >> sh) | (hi << (64 - sh)));
-      le &= kmaskLE;  // base p+i at bits [2i, 2i+1]
-      // N test: any N among bases [p, p+K)
-      const uint32_t nw = pp >> 6, nsh = pp & 63;
-      uint64_t nlo = s_nmask[nw], nhi = s_nmask[nw + 1];
-      uint64_t nb = (nsh == 0) ? nlo : ((nlo >> nsh) | (nhi << (64 - nsh)));
-      nb &= (K >= 64) ? ~0ULL : ((1ULL << K) - 1);
-      // convert to the table's big-endian packing (first base most significant): reverse 2-bit groups
-      uint64_t x = le;
-      x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-      x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-      x = __builtin_bswap64(x);
-      kmers[g] = x >> (64 - kbits);
-      maybeG[g] = valid && (nb == 0);
-      fword[g] = ~0ULL; fmask[g] = 0;
-      if (T.filter) {   // presence filter first: one 8-byte word from a cache-resident array
-        const uint64_t h = filter_hash(kmers[g]);
-        fmask[g] = filter_mask(h);
-        fword[g] = T.filter[maybeG[g] ? __umul64hi(h, T.filterWords) : 0ull];
-      }
+  for (uint32_t p = threadIdx.x; p < cnt; p += COV_THREADS) {
+    // little-endian packed window: base i at bits [2i,2i+1] of the bit stream
+    const uint32_t bit = 2 * p;
+    const uint32_t w = bit >> 6, sh = bit & 63;
+    uint64_t lo = s_pack[w], hi = s_pack[w + 1];
+    uint64_t le = (sh == 0) ? lo : ((lo >> sh) | (hi << (64 - sh)));
+    le &= kmaskLE;  // base p+i at bits [2i, 2i+1]
+    // N test: any N among bases [p, p+K)
+    const uint32_t nw = p >> 6, nsh = p & 63;
+    uint64_t nlo = s_nmask[nw], nhi = s_nmask[nw + 1];
+    uint64_t nb = (nsh == 0) ? nlo : ((nlo >> nsh) | (nhi << (64 - nsh)));
+    nb &= (K >= 64) ? ~0ULL : ((1ULL << K) - 1);
+    // convert to the table's big-endian packing (first base most significant): reverse 2-bit groups
+    uint64_t x = le;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);
+    const uint64_t kmer = x >> (64 - kbits);
+    uint32_t c = 0, j = 0;
+    bool maybe = (nb == 0);
+    if (maybe && T.filter) {   // presence filter first: one 8-byte word from a cache-resident array
+      const uint64_t h = filter_hash(kmer), m = filter_mask(h);
+      maybe = (T.filter[__umul64hi(h, T.filterWords)] & m) == m;
     }
-#pragma unroll
-    for (int g = 0; g < GRP; ++g) {
-      const uint32_t p = p0g + (uint32_t)g * COV_THREADS;
-      if (p >= cnt) continue;
-      const uint64_t kmer = kmers[g];
-      uint32_t c = 0, j = 0;
-      const bool maybe = maybeG[g] && ((fword[g] & fmask[g]) == fmask[g]);
-      if (maybe) dev_get_count(T, kmer, c, j);
-      if (c != 0) {
-        // a k-mer of the table: its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this
-        // MIN_COUNT) ride in the colour word's upper half — the anchor search asks for them position by position
-        // (Explorer.cpp:449,515) and would otherwise probe, one dependent access at a time
-        const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
-        BucketRegs br;
-        uint32_t dR = 0, dL = 0;
-        if (probe_bucket(T.right, T.capacity, kmer & m1, br))
-          dR = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
-        if (probe_bucket(T.left, T.capacity, kmer >> 2, br))
-          dL = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
-        j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
-      }
-      out[p] = make_uint2(c, j);
-      local_in += (c > min_count) ? 1 : 0;
+    if (maybe) dev_get_count(T, kmer, c, j);
+    if (c != 0) {
+      // a k-mer of the table: its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this
+      // MIN_COUNT) ride in the colour word's upper half — the anchor search asks for them position by position
+      // (Explorer.cpp:449,515) and would otherwise probe, one dependent access at a time
+      const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
+      BucketRegs br;
+      uint32_t dR = 0, dL = 0;
+      if (probe_bucket(T.right, T.capacity, kmer & m1, br))
+        dR = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
+      if (probe_bucket(T.left, T.capacity, kmer >> 2, br))
+        dL = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
+      j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
     }
+    out[p] = make_uint2(c, j);
+    local_in += (c > min_count) ? 1 : 0;
   }
   // block reduction of local_in
   for (int off = 32; off > 0; off >>= 1) local_in += __shfl_down(local_in, off, 64);
