@@ -945,10 +945,10 @@ TALC_D SeedExt seedext_plain(int refLen, int candLen, int extCols, int extRows, 
 // the extensions of getSeedAndExtension for every x-drop in [0, xHi] from one wavefront run (wave_xdrop_wfa_multi):
 // resCols[x], resRows[x] as wave_xdrop_wfa(x) would report them.  false = not available (ask x by x).
 TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xHi, int* resCols,
-                                      int* resRows) {
+                                      int* resRows, int* resScore) {
   PROF_DECL;
   refLen = uni(refLen); candLen = uni(candLen); xHi = uni(xHi); ref = uni_ptr(ref); cand = uni_ptr(cand);
-  resCols = (int*)uni_ptr(resCols); resRows = (int*)uni_ptr(resRows);
+  resCols = (int*)uni_ptr(resCols); resRows = (int*)uni_ptr(resRows); resScore = (int*)uni_ptr(resScore);
   const int K = (int)X.P.K;
   const int S = X.dirRight ? K - 1 : K;
   const bool state = !(refLen < candLen);
@@ -962,8 +962,8 @@ TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint
   unsigned long long ncells = 0;
   const int ndiagonals = min(xHi, qlen) + min(xHi, dlen) + 1;
   int rc = -1;
-  if (ndiagonals <= 63) rc = wave_xdrop_wfa_multi<1>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells);
-  else if (ndiagonals <= 127) rc = wave_xdrop_wfa_multi<2>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, ncells);
+  if (ndiagonals <= 63) rc = wave_xdrop_wfa_multi<1>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, resScore, ncells);
+  else if (ndiagonals <= 127) rc = wave_xdrop_wfa_multi<2>(seq2 + S, qlen, seq1 + S, dlen, xHi, stage, STAGE, resCols, resRows, resScore, ncells);
   PROF_END(PF_XDROP);
   X.cells += ncells;
   WSYNC();   // lane 0's results are read by every lane
@@ -1012,8 +1012,10 @@ TALC_DN void record_edge(int set, int t, int len0) {
   // the loop below asks for x, x-1, x-2, ... : all of them come out of one wavefront run when the band fits
   int* const resCols = X.dpG;
   int* const resRows = X.dpG + X.C.dpCap;
+  int* const resScore = X.dpG + 2ull * X.C.dpCap;   // ([0, 128): below the phased x-drop's hand-over area)
   bool multi = false;
-  if (xdrop1 >= 1 && (uint32_t)(xdrop1 + 1) <= X.C.dpCap) multi = seed_and_extension_multi(A, lenA, Bq, lenB, xdrop1, resCols, resRows);
+  if (xdrop1 >= 1 && (uint32_t)(xdrop1 + 1) <= X.C.dpCap && xdrop1 < 128)
+    multi = seed_and_extension_multi(A, lenA, Bq, lenB, xdrop1, resCols, resRows, resScore);
   auto ext_at = [&](int x) -> SeedExt {
     if (multi && x >= 0) return seedext_plain(lenA, lenB, uni(resCols[x]), uni(resRows[x]), x);
     return seed_and_extension(A, lenA, Bq, lenB, x, false);
@@ -1026,6 +1028,16 @@ TALC_DN void record_edge(int set, int t, int len0) {
     nxt = ext_at(xdrop1);
     if (nxt.lenHistExt < cur.lenHistExt) goFurther = false;
   } while (goFurther & (xdrop1 > 0));
+  // `cur` is the extension for x = xdrop1 + 1.  Its score (Trail.cpp:408-434: minus the edit distance of the two
+  // extensions) is the cost of the cell the run reported, when both start with the same anchor (seed_and_extension)
+  bool haveScore = false;
+  int multiScore = 0;
+  if (multi && !cur.stop) {
+    const int sc = uni(resScore[xdrop1 + 1]);
+    const int S = X.dirRight ? K - 1 : K;
+    const int l = lane_id();
+    if (sc <= 0 && ballot64(l < S && ((gcu8)A)[l < S ? l : 0] != ((gcu8)Bq)[l < S ? l : 0]) == 0ull) { haveScore = true; multiScore = sc; }
+  }
   // score of the retained extension (Trail.cpp:408-434)
   PROF_BEGIN();
   double score;
@@ -1034,8 +1046,8 @@ TALC_DN void record_edge(int set, int t, int len0) {
     // score of the retained extension (Trail.cpp:408-434) and computePercentID (Trajectory.cpp:505-528):
     // -edit distance and LCS / max length of the same two extensions
     int es, lcs;
-    edit_and_lcs(A, cur.lenRefExt, Bq, cur.lenHistExt, es, lcs, !cur.stop, 0);
-    score = cur.stop ? (double)cur.score : (double)es;
+    edit_and_lcs(A, cur.lenRefExt, Bq, cur.lenHistExt, es, lcs, !cur.stop && !haveScore, 0);
+    score = cur.stop ? (double)cur.score : (haveScore ? (double)multiScore : (double)es);
     const double lenMax = (double)max(cur.lenRefExt, cur.lenHistExt);
     idscore = (double)lcs / lenMax;
   }
@@ -2269,14 +2281,22 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
   } else if (mode == 5) {
     // mode 5: every x in [0, p0] from seed_and_extension_multi against seed_and_extension(x):
     // out[0] = 1 if the multi form was available, out[1] = number of x that differ, out[2] = the first such x
-    int* rc_ = X.dpG; int* rr_ = X.dpG + X.C.dpCap;
-    const bool ok = seed_and_extension_multi(a, la, b, lb, p0, rc_, rr_);
+    int* rc_ = X.dpG; int* rr_ = X.dpG + X.C.dpCap; int* rs_ = X.dpG + 2ull * X.C.dpCap;
+    const bool ok = seed_and_extension_multi(a, la, b, lb, p0, rc_, rr_, rs_);
     int nbad = 0, first = -1;
+    const int S5 = X.dirRight ? K - 1 : K;
+    const bool sameAnchor = ballot64(lane_id() < S5 && lane_id() < la && lane_id() < lb && a[lane_id() < la ? lane_id() : 0] != b[lane_id() < lb ? lane_id() : 0]) == 0ull && la >= S5 && lb >= S5;
     if (ok) {
       for (int x = 0; x <= p0; ++x) {
         const SeedExt m = seedext_plain(la, lb, uni(rc_[x]), uni(rr_[x]), x);
+        const int msc = uni(rs_[x]);
         const SeedExt e = seed_and_extension(a, la, b, lb, x, false);
-        if (m.lenRefExt != e.lenRefExt || m.lenHistExt != e.lenHistExt || m.posOnRef != e.posOnRef || m.stop != e.stop || m.score != e.score) {
+        bool bad = (m.lenRefExt != e.lenRefExt || m.lenHistExt != e.lenHistExt || m.posOnRef != e.posOnRef || m.stop != e.stop || m.score != e.score);
+        if (!e.stop && msc <= 0 && sameAnchor) {   // the score of the reported cell = what the scoring form returns
+          const SeedExt es = seed_and_extension(a, la, b, lb, x, true);
+          bad |= (es.score != msc);
+        }
+        if (bad) {
           if (first < 0) first = x;
           ++nbad;
         }

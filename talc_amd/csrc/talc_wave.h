@@ -639,11 +639,12 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 // x-drop leaves uninitialised (|k| = x at anti-diagonal x, for x >= 2): a run with x = e never starts diagonal
 // |k| = e from that cell.  So level e is taken once without that rule (the state larger x continue from), and the
 // result for x = e is selected from a copy in which the two diagonals |k| = e are dropped if that cell was their
-// only way in.  resCols[x] / resRows[x] (global memory, xHi + 1 entries) receive what wave_xdrop_wfa(x) reports.
+// only way in.  resCols[x] / resRows[x] / resScore[x] (global memory, xHi + 1 entries) receive what wave_xdrop_wfa(x) reports.
 // Returns -1 when the band does not fit (the caller then asks x by x).
 template <int NR>
 TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int xHi,
-                                uint8_t TALC_AS3* stage, int stageCap, int* resCols, int* resRows, unsigned long long& cells) {
+                                uint8_t TALC_AS3* stage, int stageCap, int* resCols, int* resRows, int* resScore,
+                                unsigned long long& cells) {
   gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
   qlen = uni(qlen); dlen = uni(dlen); xHi = uni(xHi);
@@ -696,13 +697,14 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
     for (int s = 0; s < NR; ++s) hit |= ballot64(f[s] == corner);
     return hit != 0ull;
   };
-  auto emit_corner_from = [&](int xFrom) {   // every x >= xFrom reaches the far corner
-    for (int x = xFrom + l; x <= xHi; x += 64) { resCols[x] = qlen; resRows[x] = dlen; }
+  // resScore[x]: the score wave_xdrop_wfa(x) reports (minus the cost of the reported cell), or 1 when it reports none
+  auto emit_corner_from = [&](int xFrom, int level) {   // every x >= xFrom reaches the far corner, at this level
+    for (int x = xFrom + l; x <= xHi; x += 64) { resCols[x] = qlen; resRows[x] = dlen; resScore[x] = -level; }
   };
   auto emit_selected = [&](int x, const int (&f)[NR], const int (&lev)[NR]) {
     int c = 0, r = 0, sc = 0;
-    if (!wfa_select<NR>(f, lev, kmin, kmax, qlen, dlen, c, r, sc)) { c = 0; r = 0; }
-    if (l == 0) { resCols[x] = c; resRows[x] = r; }
+    if (!wfa_select<NR>(f, lev, kmin, kmax, qlen, dlen, c, r, sc)) { c = 0; r = 0; sc = 1; }
+    if (l == 0) { resCols[x] = c; resRows[x] = r; resScore[x] = sc; }
   };
   {
     int a0[NR]; bool act0[NR];
@@ -714,7 +716,7 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
     for (int s = 0; s < NR; ++s) if (64 * s + l == j0) F[s] = a0[s];
   }
   unsigned long long work = 0;
-  if (hits(F)) { emit_corner_from(0); return 1; }
+  if (hits(F)) { emit_corner_from(0, 0); return 1; }
   emit_selected(0, F, E);
   for (int e = 1; e <= xHi; ++e) {
     int rotR[NR], rotL[NR];
@@ -749,9 +751,9 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
       Ex[s] = borderOnly[s] ? eOld : E[s];
     }
     work += (unsigned long long)min(nd, 2 * e + 1);
-    if (hits(Fx)) { if (l == 0) { resCols[e] = qlen; resRows[e] = dlen; } }
+    if (hits(Fx)) { if (l == 0) { resCols[e] = qlen; resRows[e] = dlen; resScore[e] = -e; } }
     else emit_selected(e, Fx, Ex);
-    if (hits(F)) { emit_corner_from(e + 1); break; }
+    if (hits(F)) { emit_corner_from(e + 1, e); break; }
   }
   cells += work;
   return 1;
