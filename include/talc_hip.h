@@ -37,7 +37,11 @@ typedef enum talc_error {
   TALC_ERR_NOMEM = -3,       /* host or device allocation failed */
   TALC_ERR_DEVICE = -4,      /* HIP runtime error (no GPU, launch failure, ...) */
   TALC_ERR_CAPACITY = -5,    /* caller-provided output buffer too small (needed size reported) */
-  TALC_ERR_STATE = -6        /* call sequence error (e.g. table not uploaded) */
+  TALC_ERR_STATE = -6,       /* call sequence error (e.g. table not uploaded) */
+  /* not an error (positive): the batch is complete and valid, but some reads carry TALC_READ_ERROR — they
+   * exhausted the device scratch even in the retry pass and are returned unchanged, like any read the
+   * reference fails on (main.cpp:298-303 logs and goes on); talc_ctx_get_timing().n_failed says how many */
+  TALC_WARN_READ_ERRORS = 1
 } talc_error;
 
 /* Per-read status after the main.cpp:247-308 loop body. */
@@ -47,7 +51,8 @@ typedef enum talc_read_status {
   TALC_READ_NO_SOLID_KMER = 2,  /* main.cpp:294: log "No solid kmer could be found." */
   TALC_READ_NO_STRUCTURE = 3,   /* main.cpp:290: log "Unable to define convenient structure." */
   TALC_READ_ERROR = 4           /* device scratch exhausted even after the retry pass; the read is
-                                   passed through unchanged and the batch call returns an error */
+                                   passed through unchanged and talc_batch_correct returns
+                                   TALC_WARN_READ_ERRORS (> 0: the other records are valid) */
 } talc_read_status;
 
 /* The reference's process globals (Settings.cpp:33-63) plus its hard-coded tunables
@@ -150,6 +155,9 @@ void talc_table_destroy(talc_table* t);
  *   Read(id, seq); getLength()>K; reCoverage(); defineStructure2(); correct2(); getCorrSeq()
  * (Read.hpp:43-77) including the -rev handling of main.cpp:253,286. */
 
+/* p->k and p->min_count must be the table's: the fast-forward reads "exactly one successor >= MIN_COUNT" as
+ * "the other three are absent" (tagNextNodes, Explorer.cpp:1281-1297), which only holds when the table was
+ * filtered with the same MIN_COUNT (Jellyfish.cpp:260). */
 int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** out);
 void talc_ctx_destroy(talc_ctx* c);
 

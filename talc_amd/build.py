@@ -19,11 +19,41 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+def _digest(sources, cmd):
+    """Content hash of every source a target depends on plus the command line that builds it."""
+    import hashlib
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for s in sorted(sources):
+        if os.path.exists(s):
+            h.update(os.path.basename(s).encode())
+            with open(s, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def _build_if_stale(target, sources, cmd, force=False):
+    """Rebuild `target` unless it exists and was built from exactly these sources with this command.  The stamp
+    (<target>.srchash) holds content hashes, not mtimes: a snapshot copied to the GPU box keeps no useful mtimes,
+    and a binary older than HEAD must never be what the tests run."""
+    stamp = target + ".srchash"
+    want = _digest(sources, cmd)
+    if not force and os.path.exists(target) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == want:
+                return False
+    _run(cmd)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
+    return True
+
+
+def source_hash(target_name="libtalc_hip.so"):
+    """The stamp of a built target (None if absent): recorded in bench.py's JSON line."""
+    try:
+        with open(os.path.join(OUT, target_name + ".srchash")) as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def _run(cmd):
@@ -36,7 +66,7 @@ def _deps(*names):
     for n in names:
         out.append(os.path.join(CSRC, n))
     for f in os.listdir(CSRC):
-        if f.endswith((".h", ".hpp", ".cuh", ".hip.h")):
+        if f.endswith((".h", ".hpp", ".cuh", ".inc", ".hip")):   # every header and every included source
             out.append(os.path.join(CSRC, f))
     for f in os.listdir(INCLUDE):
         out.append(os.path.join(INCLUDE, f))
@@ -47,8 +77,7 @@ def build_synth(force=False):
     os.makedirs(OUT, exist_ok=True)
     tgt = os.path.join(OUT, "libtalc_synth.so")
     src = os.path.join(CSRC, "synth.cpp")
-    if force or _newer(tgt, [src]):
-        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", src, "-o", tgt])
+    _build_if_stale(tgt, [src], ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", src, "-o", tgt], force)
     return tgt
 
 
@@ -56,9 +85,9 @@ def build_pure(force=False):
     """Host build of the host/device-pure product pieces for the CPU test-suite."""
     os.makedirs(OUT, exist_ok=True)
     tgt = os.path.join(OUT, "libtalc_pure.so")
-    if force or _newer(tgt, _deps("pure_capi.cpp")):
-        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-I", INCLUDE, "-I", CSRC,
-              os.path.join(CSRC, "pure_capi.cpp"), "-o", tgt])
+    _build_if_stale(tgt, _deps("pure_capi.cpp"),
+                    ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-I", INCLUDE, "-I", CSRC,
+                     os.path.join(CSRC, "pure_capi.cpp"), "-o", tgt], force)
     return tgt
 
 
@@ -69,10 +98,11 @@ def build_hip(force=False, extra_flags=(), name="libtalc_hip.so"):
     os.makedirs(OUT, exist_ok=True)
     tgt = os.path.join(OUT, name)
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    if force or _newer(tgt, _deps(*HIP_SOURCES)):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-shared", "-fopenmp",
-              "-ffp-contract=off", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC, *extra_flags, *srcs, "-o", tgt])
+    _build_if_stale(tgt, _deps(*HIP_SOURCES),
+                    [HIPCC, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-shared", "-fopenmp",
+                     "-ffp-contract=off", "-fno-gpu-rdc",
+                     "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC, *extra_flags, *srcs, "-o", tgt],
+                    force)
     return tgt
 
 
@@ -88,9 +118,9 @@ def build_cli(force=False):
     src = os.path.join(CSRC, "talc_main.cpp")
     if not os.path.exists(src):
         return None
-    if force or _newer(tgt, _deps("talc_main.cpp")):
-        _run(["g++", "-std=c++17", "-O2", "-Wall", "-fopenmp", "-I", INCLUDE, "-I", CSRC, src, "-o", tgt,
-              "-L", OUT, "-ltalc_hip", "-Wl,-rpath,$ORIGIN"])
+    _build_if_stale(tgt, _deps("talc_main.cpp"),
+                    ["g++", "-std=c++17", "-O2", "-Wall", "-fopenmp", "-I", INCLUDE, "-I", CSRC, src, "-o", tgt,
+                     "-L", OUT, "-ltalc_hip", "-Wl,-rpath,$ORIGIN"], force)
     return tgt
 
 

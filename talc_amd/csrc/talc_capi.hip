@@ -381,6 +381,8 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   if (rc) return rc;
   if (!t || !out) return fail(TALC_ERR_INVALID, "null argument");
   if (p->k != t->h.p.k) return fail(TALC_ERR_INVALID, "k mismatch between params (%u) and table (%u)", p->k, t->h.p.k);
+  if (p->min_count != t->h.p.min_count)
+    return fail(TALC_ERR_INVALID, "min_count mismatch between params (%u) and the table it was filtered with (%u)", p->min_count, t->h.p.min_count);
   TableView v;
   rc = table_view(t, device, v);
   if (rc) return rc;

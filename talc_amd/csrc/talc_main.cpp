@@ -309,7 +309,10 @@ int main(int argc, const char** argv) {
   std::map<uint64_t, std::unique_ptr<Chunk>> finished;
   std::ofstream lf;
   std::atomic<bool> failed{false};
+  std::mutex failMu;
   std::string failMsg;
+  std::atomic<uint64_t> readErrors{0};
+  auto setFailed = [&]() { std::lock_guard<std::mutex> g(failMu); if (!failed) failMsg = talc_last_error(); failed = true; };
   auto readChunk = [&]() -> std::unique_ptr<Chunk> {
     std::lock_guard<std::mutex> g(rdMu);
     std::unique_ptr<Chunk> c(new Chunk());
@@ -330,8 +333,11 @@ int main(int argc, const char** argv) {
     while (!finished.empty() && finished.begin()->first == nextToWrite) {
       Chunk& k = *finished.begin()->second;
       for (size_t r = 0; r < k.ids.size(); ++r) {
+        // (a read that exhausted the device scratch is written through unchanged, like any read the reference fails on:
+        //  it logs and goes on, main.cpp:298-303)
         const char* msg = k.status[r] == TALC_READ_NO_STRUCTURE ? "Unable to define convenient structure."       // main.cpp:290
-                          : k.status[r] == TALC_READ_NO_SOLID_KMER ? "No solid kmer could be found." : nullptr;  // main.cpp:294
+                          : k.status[r] == TALC_READ_NO_SOLID_KMER ? "No solid kmer could be found."             // main.cpp:294
+                          : k.status[r] == TALC_READ_ERROR ? "Device scratch exhausted; read left uncorrected." : nullptr;
         if (msg) {
           if (!lf.is_open()) lf.open(logFile, std::ios_base::app);
           lf << "[Read: " << k.ids[r] << " ]: " << msg << std::endl;
@@ -362,7 +368,7 @@ int main(int argc, const char** argv) {
   };
   auto worker = [&](int device) {
     talc_ctx* ctx = nullptr;
-    if (device >= 0 && talc_ctx_create(table, &o.p, device, &ctx) != TALC_OK) { failMsg = talc_last_error(); failed = true; return; }
+    if (device >= 0 && talc_ctx_create(table, &o.p, device, &ctx) != TALC_OK) { setFailed(); return; }
     while (!failed) {
       std::unique_ptr<Chunk> c = readChunk();
       if (!c) break;
@@ -372,15 +378,18 @@ int main(int argc, const char** argv) {
         const uint32_t n = (uint32_t)c->ids.size();
         c->out.resize(n); c->status.assign(n, TALC_READ_SKIPPED_SHORT);
         talc_batch* b = nullptr;
-        if (talc_batch_create(ctx, c->bases.data(), c->offsets.data(), n, &b) != TALC_OK) { failMsg = talc_last_error(); failed = true; break; }
-        if (talc_batch_correct(ctx, b) != TALC_OK) { failMsg = talc_last_error(); failed = true; }
+        if (talc_batch_create(ctx, c->bases.data(), c->offsets.data(), n, &b) != TALC_OK) { setFailed(); break; }
+        // < 0: a real HIP / argument error stops the run; TALC_WARN_READ_ERRORS (> 0) is a complete batch in which some
+        // reads kept their input sequence (status TALC_READ_ERROR -> a .log line), and the run goes on
+        const int crc = talc_batch_correct(ctx, b);
+        if (crc < 0) { setFailed(); talc_batch_destroy(b); break; }
         const uint64_t total = talc_batch_corrected_bytes(b);
         std::vector<char> buf(std::max<uint64_t>(total, 1));
         std::vector<uint64_t> oo(n + 1);
-        if (talc_batch_fetch_corrected(ctx, b, buf.data(), total, oo.data(), c->status.data()) != TALC_OK) { failMsg = talc_last_error(); failed = true; talc_batch_destroy(b); break; }
+        if (talc_batch_fetch_corrected(ctx, b, buf.data(), total, oo.data(), c->status.data()) != TALC_OK) { setFailed(); talc_batch_destroy(b); break; }
         for (uint32_t i = 0; i < n; ++i) c->out[i].assign(buf.data() + oo[i], oo[i + 1] - oo[i]);
+        if (crc > 0) for (uint32_t i = 0; i < n; ++i) readErrors += c->status[i] == TALC_READ_ERROR ? 1 : 0;
         talc_batch_destroy(b);
-        if (failed) break;
       }
       writeReady(std::move(c));
     }
@@ -400,6 +409,7 @@ int main(int argc, const char** argv) {
     return 2;
   }
   if (table) talc_table_destroy(table);
+  if (readErrors) std::cerr << "talc: " << readErrors << " read(s) exhausted the device scratch and were written uncorrected (see " << logFile << ")\n";
   std::cout << "[TALC]: Looks like we are done now." << std::endl;
   fprintf(stderr, "[talc] scan=%.3fs table=%.3fs read+correct+write=%.3fs (%.3g bases/s, %llu batches) total=%.3fs\n", secs(t0, t1),
           secs(t1, t2), secs(t2, t3), secs(t2, t3) > 0 ? (double)basesTotal / secs(t2, t3) : 0.0, (unsigned long long)nextIndex, secs(t0, t3));

@@ -138,9 +138,14 @@ def lib():
     return _LIB
 
 
+WARN_READ_ERRORS = 1   # TALC_WARN_READ_ERRORS: the batch is valid, some reads carry READ_ERROR
+
+
 def _chk(rc):
-    if rc != 0:
+    """Negative codes are errors; positive ones (TALC_WARN_READ_ERRORS) are returned to the caller."""
+    if rc < 0:
         raise TalcError("libtalc_hip error %d: %s" % (rc, lib().talc_last_error().decode(errors="replace")))
+    return rc
 
 
 def default_params(**kw):
@@ -319,7 +324,8 @@ class Batch:
         return c, j, ko, nin
 
     def correct(self):
-        _chk(lib().talc_batch_correct(self.ctx._h, self._h))
+        """0, or WARN_READ_ERRORS when some reads exhausted the device scratch (status READ_ERROR, passed through)."""
+        return _chk(lib().talc_batch_correct(self.ctx._h, self._h))
 
     def fetch_corrected(self):
         total = int(lib().talc_batch_corrected_bytes(self._h))

@@ -15,14 +15,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _native_built():
-    """Build whatever is missing (host libs + oracle always; the HIP library only if absent:
-    it is prebuilt in-tree and travels to the GPU box)."""
+    """Build whatever is missing or older than its sources (every builder is mtime-incremental, so a
+    prebuilt, up-to-date library that travelled to the GPU box is left alone)."""
     from talc_amd import build as B
     B.build_synth()
     B.build_pure()
     B.build_oracle()
-    if not os.path.exists(os.path.join(B.OUT, "libtalc_hip.so")):
-        B.build_hip()
+    B.build_hip()
+    B.build_cli()
     yield
 
 
