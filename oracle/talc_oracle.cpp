@@ -10,6 +10,7 @@
 //    and-ed with false anyway).
 //  * stdout debug prints (DEBUG_READ/DEBUG_TEST/DEBUG_USER) are not reproduced.
 #include "talc_oracle.hpp"
+#include <omp.h>
 
 #include <algorithm>
 #include <cmath>
@@ -157,6 +158,50 @@ void Table::insertPacked(const uint64_t* keys, const uint32_t* counts, const uin
     return;
   }
   if (fK_ == 0) fK_ = K;
+  if (fkeys_.empty() && n > (1u << 15)) {   // sized once for the whole array (same content, no regrowth)
+    size_t cap = 1u << 16;
+    while (cap < 2 * (size_t)n + 2) cap *= 2;
+    fkeys_.assign(cap, kEmpty);
+    fvals_.assign(cap, colouredCount(0, 0));
+    // Parallel over slot ranges: a thread takes, in array order, the keys whose home slot lies in its range, so the
+    // winner among duplicates is the one a serial pass picks (std::map::insert, Jellyfish.cpp:262); a probe sequence
+    // that would leave the range is put off to the serial pass below.
+    int T = omp_get_max_threads();
+    if (T > 32) T = 32;
+    if (n < (1u << 20)) T = 1;
+    std::vector<std::vector<uint64_t>> later(T);
+    std::vector<uint64_t> added(T, 0);
+    const uint64_t mask = cap - 1;
+#pragma omp parallel num_threads(T)
+    {
+      const int t = omp_get_thread_num();
+      const uint64_t lo = cap / T * t, hi = (t == T - 1) ? cap : cap / T * (t + 1);
+      uint64_t nadd = 0;
+      for (uint64_t i = 0; i < n; ++i) {
+        uint64_t sl = mix64(keys[i]) & mask;
+        if (sl < lo || sl >= hi) continue;
+        while (sl < hi && fkeys_[sl] != kEmpty && fkeys_[sl] != keys[i]) ++sl;
+        if (sl >= hi) { later[t].push_back(i); continue; }
+        if (fkeys_[sl] == keys[i]) continue;
+        fkeys_[sl] = keys[i];
+        fvals_[sl] = colouredCount(counts[i], jcounts ? jcounts[i] : 0);
+        ++nadd;
+      }
+      added[t] = nadd;
+    }
+    for (int t = 0; t < T; ++t) fcount_ += added[t];
+    std::vector<uint64_t> rest;
+    for (int t = 0; t < T; ++t) rest.insert(rest.end(), later[t].begin(), later[t].end());
+    std::sort(rest.begin(), rest.end());   // array order again
+    for (uint64_t i : rest) {
+      uint64_t slot;
+      if (flatFind(keys[i], slot)) continue;
+      fkeys_[slot] = keys[i];
+      fvals_[slot] = colouredCount(counts[i], jcounts ? jcounts[i] : 0);
+      fcount_++;
+    }
+    return;
+  }
   for (uint64_t i = 0; i < n; ++i) {
     if ((fcount_ + 1) * 2 > fkeys_.size()) flatGrow();
     uint64_t slot;

@@ -77,7 +77,7 @@ def build_synth(force=False):
     os.makedirs(OUT, exist_ok=True)
     tgt = os.path.join(OUT, "libtalc_synth.so")
     src = os.path.join(CSRC, "synth.cpp")
-    _build_if_stale(tgt, [src], ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", src, "-o", tgt], force)
+    _build_if_stale(tgt, [src], ["g++", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared", "-Wall", src, "-o", tgt], force)
     return tgt
 
 

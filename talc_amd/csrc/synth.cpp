@@ -72,6 +72,11 @@ struct Synth {
   std::vector<uint64_t> tstart;       // transcript start offsets (+ sentinel)
   std::vector<double> tlambda;
   std::vector<double> tcum;           // cumulative weight length*lambda
+  // mixed_lengths (config 5): transcripts by ascending length and the cumulative weights in that order, so that a
+  // read of length L is drawn (again with probability ~ length*lambda) among the transcripts that can hold it
+  std::vector<uint32_t> byLen;
+  std::vector<uint64_t> lenSorted;
+  std::vector<double> cumSorted;
   std::vector<uint64_t> dkeys;
   std::vector<uint32_t> dcounts;
   std::vector<uint64_t> jkeys;
@@ -87,7 +92,8 @@ void buildTranscriptome(Synth& S) {
   uint64_t total = 0;
   S.tstart.push_back(0);
   while (total < S.sp.target_kmers) {
-    double len = std::exp(std::log(1500.0) + 0.6 * rng.normal());
+    // config 5 (mixed read lengths up to 20 kb) needs transcripts that long: a wider length distribution there
+    double len = S.sp.mixed_lengths ? std::exp(std::log(4000.0) + 1.0 * rng.normal()) : std::exp(std::log(1500.0) + 0.6 * rng.normal());
     if (len < 300) len = 300;
     if (len > 30000) len = 30000;
     uint64_t L = (uint64_t)len;
@@ -122,10 +128,96 @@ void buildTranscriptome(Synth& S) {
     c += (double)(S.tstart[t + 1] - S.tstart[t]) * S.tlambda[t];
     S.tcum.push_back(c);
   }
+  if (S.sp.mixed_lengths) {
+    const size_t n = S.tlambda.size();
+    S.byLen.resize(n);
+    for (size_t t = 0; t < n; ++t) S.byLen[t] = (uint32_t)t;
+    std::stable_sort(S.byLen.begin(), S.byLen.end(), [&](uint32_t a, uint32_t b) {
+      return S.tstart[a + 1] - S.tstart[a] < S.tstart[b + 1] - S.tstart[b];
+    });
+    double cs = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t t = S.byLen[i];
+      const uint64_t len = S.tstart[t + 1] - S.tstart[t];
+      cs += (double)len * S.tlambda[t];
+      S.lenSorted.push_back(len);
+      S.cumSorted.push_back(cs);
+    }
+  }
+}
+
+// gcd for the affine line permutation below
+uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; }
+
+// The same kind of dump for the big configurations (>= 100 M k-mers: BASELINE configs 3-5), built in parallel: one
+// generator per transcript / per block of extra lines instead of one stream for the whole file, and the line order
+// scattered by an affine permutation of the line index instead of a serial Fisher-Yates.  Deterministic for a given
+// spec whatever the number of threads.  (Smaller configurations keep the serial form below: the committed golden
+// fixtures pin its exact output.)
+void buildDumpParallel(Synth& S) {
+  const uint32_t K = S.sp.k;
+  const uint64_t mask = (K >= 32) ? ~0ULL : ((1ULL << (2 * K)) - 1);
+  const size_t nT = S.tlambda.size();
+  std::vector<uint64_t> off(nT + 1, 0);
+  for (size_t t = 0; t < nT; ++t) {
+    const uint64_t len = S.tstart[t + 1] - S.tstart[t];
+    off[t + 1] = off[t] + (len >= K ? len - K + 1 : 0);
+  }
+  const uint64_t nTrue = off[nT];
+  const uint64_t nErr = (uint64_t)(S.sp.extra_error_frac * (double)nTrue);
+  const uint64_t nOne = (uint64_t)(S.sp.count1_frac * (double)nTrue);
+  const uint64_t N = nTrue + nErr + nOne;
+  std::vector<uint64_t> keys(N);
+  std::vector<uint32_t> counts(N);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (long t = 0; t < (long)nT; ++t) {
+    const uint64_t b = S.tstart[t], e = S.tstart[t + 1];
+    if (e - b < K) continue;
+    Rng rng((S.sp.seed ^ 0x7A1C0002ULL) + 0x9E3779B97F4A7C15ULL * (uint64_t)(t + 1));
+    uint64_t km = 0, w = off[t];
+    for (uint64_t i = b; i < e; ++i) {
+      km = ((km << 2) | S.tx[i]) & mask;
+      if (i - b + 1 >= K) {
+        uint32_t c = rng.poisson(S.tlambda[t]);
+        if (c < 2) c = 2;
+        keys[w] = km; counts[w] = c; ++w;
+      }
+    }
+  }
+  const uint64_t BLK = 1u << 16;
+  const uint64_t nExtra = nErr + nOne;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (long blk = 0; blk < (long)((nExtra + BLK - 1) / BLK); ++blk) {
+    Rng rng((S.sp.seed ^ 0x7A1C0012ULL) + 0x9E3779B97F4A7C15ULL * (uint64_t)(blk + 1));
+    const uint64_t lo = (uint64_t)blk * BLK, hi = std::min(nExtra, lo + BLK);
+    for (uint64_t i = lo; i < hi; ++i) {
+      if (i < nErr) {   // one substitution of a true k-mer, count in {2,3}
+        uint64_t km = keys[rng.below(nTrue)];
+        const uint32_t o = (uint32_t)rng.below(K);
+        const uint64_t cur = (km >> (2 * o)) & 3, nb = (cur + 1 + rng.below(3)) & 3;
+        km = (km & ~(3ULL << (2 * o))) | (nb << (2 * o));
+        keys[nTrue + i] = km; counts[nTrue + i] = 2 + (uint32_t)rng.below(2);
+      } else {          // count 1: dropped by MIN_COUNT
+        keys[nTrue + i] = rng.next() & mask; counts[nTrue + i] = 1;
+      }
+    }
+  }
+  // line i of the dump = entry (a i + b) mod N, a coprime to N
+  uint64_t a = 0x9E3779B97F4A7C15ULL % N, b0 = (S.sp.seed * 0xD1B54A32D192ED03ULL + 12345) % N;
+  if (a < 2) a = 2;
+  while (gcd64(a, N) != 1) ++a;
+  S.dkeys.resize(N); S.dcounts.resize(N);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)N; ++i) {
+    const uint64_t j = (uint64_t)(((unsigned __int128)a * (uint64_t)i + b0) % N);
+    S.dkeys[i] = keys[j]; S.dcounts[i] = counts[j];
+  }
+  S.dumpBuilt = true;
 }
 
 void buildDump(Synth& S) {
   if (S.dumpBuilt) return;
+  if (S.sp.target_kmers >= 100000000ULL) { buildDumpParallel(S); return; }
   const uint32_t K = S.sp.k;
   const uint64_t mask = (K >= 32) ? ~0ULL : ((1ULL << (2 * K)) - 1);
   Rng rng(S.sp.seed ^ 0x7A1C0002ULL);
@@ -217,10 +309,22 @@ void makeRead(const Synth& S, uint64_t index, std::string& out) {
     for (uint64_t i = 0; i < L; ++i) out.push_back(D[rng.next() >> 62]);
     return;
   }
-  // transcript chosen with probability ~ length * lambda
-  const double w = rng.uniform() * S.tcum.back();
-  size_t t = (size_t)(std::lower_bound(S.tcum.begin(), S.tcum.end(), w) - S.tcum.begin());
-  if (t >= S.tlambda.size()) t = S.tlambda.size() - 1;
+  // transcript chosen with probability ~ length * lambda (mixed lengths: among those at least L long, so that the
+  // read-length distribution really reaches 20 kb instead of being clipped to short transcripts)
+  size_t t;
+  if (S.sp.mixed_lengths) {
+    if (L > S.lenSorted.back()) L = S.lenSorted.back();
+    const size_t i0 = (size_t)(std::lower_bound(S.lenSorted.begin(), S.lenSorted.end(), L) - S.lenSorted.begin());
+    const double base = i0 ? S.cumSorted[i0 - 1] : 0.0;
+    const double w = base + rng.uniform() * (S.cumSorted.back() - base);
+    size_t i = (size_t)(std::lower_bound(S.cumSorted.begin() + (long)i0, S.cumSorted.end(), w) - S.cumSorted.begin());
+    if (i >= S.byLen.size()) i = S.byLen.size() - 1;
+    t = S.byLen[i];
+  } else {
+    const double w = rng.uniform() * S.tcum.back();
+    t = (size_t)(std::lower_bound(S.tcum.begin(), S.tcum.end(), w) - S.tcum.begin());
+    if (t >= S.tlambda.size()) t = S.tlambda.size() - 1;
+  }
   const uint64_t b = S.tstart[t], e = S.tstart[t + 1];
   if (L > e - b) L = e - b;
   const uint64_t start = b + rng.below(e - b - L + 1);
@@ -299,17 +403,40 @@ void synth_junction_arrays(void* h, uint64_t* keys, int64_t* jcounts) {
   memcpy(jcounts, S.jcounts.data(), S.jcounts.size() * 8);
 }
 
-// reads [first, first+n): pass bases=NULL to get the total size in offsets[n]
+// reads [first, first+n): pass bases=NULL to get the total size in offsets[n].  Every read depends on (seed, index)
+// only, so large requests are generated in parallel.
 void synth_reads(void* h, uint64_t first, uint32_t n, char* bases, uint64_t* offsets) {
   const Synth& S = *(Synth*)h;
-  std::string r;
-  uint64_t pos = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    makeRead(S, first + i, r);
-    offsets[i] = pos;
-    if (bases) memcpy(bases + pos, r.data(), r.size());
-    pos += r.size();
+  if (n < 4096) {
+    std::string r;
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      makeRead(S, first + i, r);
+      offsets[i] = pos;
+      if (bases) memcpy(bases + pos, r.data(), r.size());
+      pos += r.size();
+    }
+    offsets[n] = pos;
+    return;
   }
+  if (bases) {   // offsets[] hold the result of the sizing call: fill in place
+#pragma omp parallel
+    {
+      std::string r;
+#pragma omp for schedule(dynamic, 256)
+      for (long i = 0; i < (long)n; ++i) { makeRead(S, first + (uint64_t)i, r); memcpy(bases + offsets[i], r.data(), r.size()); }
+    }
+    return;
+  }
+  std::vector<uint64_t> len(n);
+#pragma omp parallel
+  {
+    std::string r;
+#pragma omp for schedule(dynamic, 256)
+    for (long i = 0; i < (long)n; ++i) { makeRead(S, first + (uint64_t)i, r); len[i] = r.size(); }
+  }
+  uint64_t pos = 0;
+  for (uint32_t i = 0; i < n; ++i) { offsets[i] = pos; pos += len[i]; }
   offsets[n] = pos;
 }
 

@@ -80,17 +80,27 @@ struct TrailSetLayout {
   static constexpr uint64_t bytes = buf + 4ull * TCAP;
 };
 
-static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, bool tiny = false) {
+// Scratch of one wave.  A Trail is at most K + PATH_MAXLENGTH = 1.2 gap + 4 K bases long (Explorer.cpp:919,1036), and
+// the pool holds NBUF such buffers, so the pool is what the slot size hangs on.  The first pass sizes the buffers for
+// gaps up to `seqLimit` bases (nearly every gap of a noisy read is a few hundred bases, whatever the read's length:
+// 20 kb reads would otherwise cost 14 MB per wave); a search that outgrows its buffer raises OVF_SEQ and the read goes
+// to the retry passes, which size everything from the batch's longest read (seqLimit = 0: a path can then never
+// outgrow its buffer) and multiply the counted capacities (anchors, recorded bridges) by `scale`.
+static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, uint32_t seqLimit, bool tiny = false) {
   SearchCaps c;
   memset(&c, 0, sizeof c);
   const uint64_t Lm = maxLen;
-  c.seqCap = (uint32_t)align_up((uint64_t)(1.2 * (double)Lm) + 4ull * K + 64, 16);
+  const uint64_t gapMax = (seqLimit && seqLimit < Lm) ? seqLimit : Lm;
+  c.seqCap = (uint32_t)align_up((uint64_t)(1.2 * (double)gapMax) + 4ull * K + 64, 16);
   c.refCap = (uint32_t)align_up(Lm + 2ull * K + 64, 16);
   c.edgeCap = (uint32_t)align_up((uint64_t)c.seqCap + c.refCap, 16);
-  c.anchCap = 256 * scale;
+  // (a region of n k-mers records at most n positions: beyond that the anchor lists cannot overflow)
+  c.anchCap = (uint32_t)std::min<uint64_t>(256ull * scale, Lm + 8);
+  if (c.anchCap < 8) c.anchCap = 8;
   c.fullCap = 128 * scale;
   c.fullPool = (uint32_t)align_up((uint64_t)c.seqCap * 16 * scale, 16);
   c.dpCap = (uint32_t)align_up(std::max<uint64_t>(c.edgeCap, c.seqCap) + 8, 4);
+  if (c.dpCap < 1024) c.dpCap = 1024;   // (the phased x-drop keeps its hand-over state in these arrays)
   if (tiny) { c.anchCap = 3; c.fullCap = 1; c.fullPool = (uint32_t)align_up((uint64_t)c.seqCap, 16); }  // test hook: force the retry pass
   c.regCap = (uint32_t)(Lm / 2 + 4);
   c.weakPool = (uint32_t)align_up(out_capacity_for(Lm), 16);

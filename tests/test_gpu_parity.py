@@ -410,12 +410,31 @@ def test_trace_hook_matches_oracle(gpu_pair):
 
 
 def test_mixed_lengths_config5_shape():
-    """BASELINE config 5 shape at small scale: K=31, reads from 500 b to 20 kb."""
-    pair = PU.Pair(target_kmers=400_000, k=31, seed=41, synth_kw=dict(mixed_lengths=1))
+    """BASELINE config 5 shape at small scale: K=31, reads log-uniform from 500 b to 20 kb (the generator draws every
+    read from a transcript at least as long, so the long ones are as correctable as the short ones), 160 of them
+    against the oracle, 30+ beyond 8 kb."""
+    pair = PU.Pair(target_kmers=1_500_000, k=31, seed=41, synth_kw=dict(mixed_lengths=1))
     pair.upload(0)
-    so, st = _check(pair, 0, 120)
+    so, st = _check(pair, 0, 160, nthreads=16)
     lens = [len(s) for s in so]
-    assert max(lens) > 3000 and min(l for l in lens if l > 31) < 1500
+    assert max(lens) > 15000 and min(l for l in lens if l > 31) < 1500
+    assert sum(1 for l in lens if l > 8000) >= 30
+    long_ok = [i for i in range(len(so)) if lens[i] > 8000 and st[i] == 0]
+    assert len(long_ok) >= 25                                     # the long reads are corrected, not passed through
+    t = pair.ctx.timing()
+    assert t.n_failed == 0
+
+
+def test_long_gaps_go_through_the_retry_pass(monkeypatch):
+    """The first pass sizes the Trail buffers for gaps of TALC_SEQ_LIMIT bases (4096 by default); a longer gap
+    overflows its buffer (OVF_SEQ) and the read is redone with buffers sized from the longest read.  With the limit
+    at 64 bases most reads of a K=31 batch take that route: same records as the oracle, nothing fails."""
+    monkeypatch.setenv("TALC_SEQ_LIMIT", "64")
+    pair = PU.Pair(target_kmers=600_000, k=31, seed=43, synth_kw=dict(mixed_lengths=1))
+    pair.upload(0)
+    _check(pair, 0, 60, nthreads=16)
+    t = pair.ctx.timing()
+    assert t.n_retried >= 30 and t.n_failed == 0
 
 
 # ---------------------------------------------------------------- walk tables (fast-forward accelerator)
