@@ -2,19 +2,25 @@
 """bench.py — corrected long-read bases/sec of the TALC hot path on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
-torch.distributed.run with one rank per GPU (backend nccl = RCCL).  One "step" is one pass of
-the whole hot path (coverage probe -> structure -> path search -> reassembly) over one batch of
-synthetic long reads that is already resident in HBM, plus — for N>1 — the RCCL gather of the
-corrected records to rank 0.  Reads shard across ranks (no data-path collective), the k-mer
-table is replicated per GPU: weak scaling, every rank corrects --reads reads.
+torch.distributed.run with one rank per GPU (backend nccl = RCCL).  One "step" is one pass of the whole hot
+path (coverage probe -> structure -> path search -> reassembly) over the workload's reads, already resident
+in HBM, plus — for N>1 — the RCCL gather of the corrected records to rank 0.
 
-Workload at N=1: BASELINE.json configs[1] — 100k synthetic ONT-like reads (~2 kb, 12% error)
-against a 50M-entry synthetic k=21 k-mer dump.  Rank 0 prints ONE JSON line.
+Workloads (BASELINE.json `configs`, synthetic data):
+  N = 1  -> configs[1] ("config2"): 100 k ONT-like reads (~2 kb, 12 % error), 50 M-entry k=21 dump
+  N > 1  -> configs[2] ("config3"): 1 M reads, 200 M-entry k=21 dump — the SAME 1 M reads whatever N is (strong
+            scaling): reads are dealt to the ranks in contiguous blocks of equal bases (talc_amd.sharding.shard_bounds,
+            replaces the OpenMP loop of main.cpp:247-308), the table is built once on rank 0 and its device image
+            broadcast to the other ranks over RCCL / xGMI (replicated per GPU, no data-path collective)
+  --config 2|3|4|5 forces one of them at any N (4 = config3 + junction colours; 5 = k=31, 500 M entries, 100 k reads
+  of 500 b - 20 kb); --reads / --kmers / --k override single figures (the label then says "custom").
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -26,22 +32,90 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 COV_BYTES_PER_KMER = 25        # 16 B slot + 8 B result + 1 B base
 STEP_BYTES = 64                # 64 B per Trail-step (4 slots x 16 B)
 
+CONFIGS = {
+    2: dict(reads=100_000, kmers=50_000_000, k=21, junctions=False, mixed=False),
+    3: dict(reads=1_000_000, kmers=200_000_000, k=21, junctions=False, mixed=False),
+    4: dict(reads=1_000_000, kmers=200_000_000, k=21, junctions=True, mixed=False),
+    5: dict(reads=100_000, kmers=500_000_000, k=31, junctions=False, mixed=True),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU (config 2: 100k)")
-    ap.add_argument("--kmers", type=int, default=50_000_000, help="distinct k-mers in the synthetic dump")
-    ap.add_argument("--k", type=int, default=21)
+    ap.add_argument("--config", default="auto", help="auto (N=1: 2, N>1: 3) or one of 2, 3, 4, 5")
+    ap.add_argument("--reads", type=int, default=None, help="total reads of the workload (override)")
+    ap.add_argument("--kmers", type=int, default=None, help="distinct k-mers in the synthetic dump (override)")
+    ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="reads of the same workload timed on the CPU oracle (0 = sized for ~15 s from a pilot run)")
     ap.add_argument("--cpu-backend", choices=["flat", "map"], default="flat",
-                    help="oracle table: flat hash (quick to build) or the reference's std::map")
+                    help="oracle table: flat hash (quick to build) or the reference's std::map (SURVEY §8d)")
     ap.add_argument("--no-cpu", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host pass")
+    return ap.parse_args(argv)
+
+
+def resolve_workload(a, world):
+    """The workload's figures and its label, from the arguments alone (tests/test_abi_and_host.py pins this)."""
+    cfg = (2 if world == 1 else 3) if a.config == "auto" else int(a.config)
+    if cfg not in CONFIGS:
+        raise SystemExit("--config must be auto, 2, 3, 4 or 5")
+    w = dict(CONFIGS[cfg])
+    custom = []
+    for key in ("reads", "kmers", "k"):
+        v = getattr(a, key)
+        if v is not None and v != w[key]:
+            w[key] = v
+            custom.append(key)
+    w["config"] = cfg
+    name = "config%d" % cfg if not custom else "custom (config%d with %s changed)" % (cfg, ", ".join(custom))
+    shape = "500 b - 20 kb log-uniform" if w["mixed"] else "~2 kb"
+    w["label"] = ("%s: %d synthetic ONT-like reads in all (%s, 12%% error) sharded over %d GPU(s), %d-base synthetic "
+                  "transcriptome's k=%d k-mer dump%s, table replicated per GPU"
+                  % (name, w["reads"], shape, world, w["kmers"], w["k"], " + junction dump (--junctions)" if w["junctions"] else ""))
+    return w
+
+
+def build_table(T, synth, w, params, dev, rank, world, dist, torch, log):
+    """Rank 0 builds the table on its GPU (insertion, colouring, de-colouring: all kernels); for N > 1 its device
+    image goes to every other rank by one RCCL broadcast per bucket table and is imported there."""
+    n_dump = 0
+    table = None
+    if rank == 0:
+        keys, counts = synth.dump_arrays()
+        n_dump = len(keys)
+        table = T.Table.from_arrays(keys, counts, params, device=dev)
+        if w["junctions"]:
+            jk, jc = synth.junction_arrays()
+            table.colour(jk, jc)
+        table.decolour_repeats()
+    else:
+        keys = counts = None
+    if world > 1:
+        meta = torch.zeros(3, dtype=torch.int64, device="cuda")
+        if rank == 0:
+            meta[0], meta[1], meta[2] = table.capacity, len(table), n_dump
+        dist.broadcast(meta, src=0)
+        cap, nk, n_dump = (int(x) for x in meta.tolist())
+        t0 = time.time()
+        br = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+        bl = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            table.export_device(dev, br.data_ptr(), bl.data_ptr())
+        dist.broadcast(br, src=0)
+        dist.broadcast(bl, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            table = T.Table.import_device(params, cap, nk, br.data_ptr(), bl.data_ptr(), dev)
+        del br, bl
+        torch.cuda.empty_cache()
+        log("table image (2 x %.1f GB) broadcast over RCCL in %.1f s" % (cap * 32 / 1e9, time.time() - t0))
+    table.upload(dev)
+    return table, keys, counts, n_dump
 
 
 def main():
@@ -58,46 +132,49 @@ def main():
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
 
+    from talc_amd import build as B
     from talc_amd import lib as T
+    from talc_amd import sharding as SH
     from talc_amd.synth import Synth
 
+    log = (lambda m: print("[bench r%d] %s" % (rank, m), file=sys.stderr, flush=True))
+    w = resolve_workload(a, world)
     t_setup = time.time()
-    synth = Synth(target_kmers=a.kmers, k=a.k, seed=a.seed)
-    keys, counts = synth.dump_arrays()
-    params = T.default_params(k=a.k)
-    table = T.Table.from_arrays(keys, counts, params, device=dev)   # insertion on the GPU (untimed setup)
-    table.decolour_repeats()
+    synth = Synth(target_kmers=w["kmers"], k=w["k"], seed=a.seed, mixed_lengths=int(w["mixed"]))
+    params = T.default_params(k=w["k"], use_junctions=int(w["junctions"]))
+    table, keys, counts, n_dump = build_table(T, synth, w, params, dev, rank, world, dist, torch, log)
     n_table = len(table)
-    table.upload(dev)
     ctx = T.Context(table, params, dev)
-    # this rank's shard of the read set (weak scaling: --reads per GPU)
-    bases, offs = synth.reads(rank * a.reads, a.reads)
+    # this rank's share of the reads: contiguous blocks of (nearly) equal bases, rank order == input order
+    lengths = synth.read_lengths(0, w["reads"])
+    bounds = SH.shard_bounds(lengths, world)
+    first, n_mine = bounds[rank], bounds[rank + 1] - bounds[rank]
+    bases, offs = synth.reads(first, n_mine)
     batch = ctx.batch(bases, offs)
     n_bases = batch.n_bases
     setup_s = time.time() - t_setup
-    log = (lambda m: print("[bench r%d] %s" % (rank, m), file=sys.stderr, flush=True))
-    log("setup %.1fs: table %d k-mers (%.2f GB on device), %d reads / %d bases resident" %
-        (setup_s, n_table, table.device_bytes / 1e9, a.reads, n_bases))
-
-    from talc_amd import sharding as SH
+    log("setup %.1fs: table %d k-mers (%.2f GB on device), reads [%d, %d) of %d / %d bases resident" %
+        (setup_s, n_table, table.device_bytes / 1e9, first, first + n_mine, w["reads"], n_bases))
 
     def gather_records():
         """The 'trivial RCCL gather': corrected records of every rank -> rank 0 (device tensors,
         torch.distributed over RCCL/xGMI; rank order == input order)."""
         nbytes = batch.corrected_bytes
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda")
-        batch.copy_corrected_to_device(buf.data_ptr(), nbytes)
+        oo_, st_ = batch.copy_corrected_to_device(buf.data_ptr(), nbytes)
         if world == 1:
             return buf
-        return SH.gather_records(buf[:nbytes], dist, rank, world, dst=0)
+        # [n][offsets][status][records] per rank, assembled on the device; rank 0 receives them in rank order
+        return SH.gather_records(SH.pack_records_device(torch, buf[:nbytes], oo_, st_), dist, rank, world, dst=0)
 
     def one_step():
         batch.correct()
         return gather_records()
 
+    gathered = None
     for i in range(a.warmup):
         tw = time.time()
-        one_step()
+        gathered = one_step()
         log("warmup %d: %.2fs  %s" % (i, time.time() - tw, {k: round(v, 2) for k, v in ctx.timing().as_dict().items()}))
     tm = {k: 0.0 for k in ("encode_ms", "coverage_ms", "structure_ms", "search_ms", "emit_ms", "retry_ms")}
     if world > 1:
@@ -106,11 +183,10 @@ def main():
     t0 = time.perf_counter()
     last = None
     for _ in range(a.steps):
-        one_step()
+        gathered = one_step()
         last = ctx.timing()
         for k in tm:
             tm[k] += getattr(last, k)
-        log("step done at %.2fs" % (time.perf_counter() - t0))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -129,6 +205,13 @@ def main():
 
     out, oo, st = batch.fetch_corrected()
     status_hist = np.bincount(st, minlength=5).tolist()
+    merged_reads = None
+    if world > 1 and rank == 0 and gathered is not None:
+        # untimed: the gathered payloads merge into one record set in input order (rank 0's own records first)
+        seq_all, off_all, st_all = SH.merge_in_order([g.cpu().numpy() for g in gathered])
+        merged_reads = len(st_all)
+        if merged_reads != w["reads"] or int(off_all[-1]) != len(seq_all) or seq_all[: len(out)] != out.tobytes():
+            raise SystemExit("gathered records do not merge into the workload's %d reads" % w["reads"])
 
     result = None
     if rank == 0:
@@ -137,17 +220,8 @@ def main():
         cov_gbs = (last.n_kmers * COV_BYTES_PER_KMER / cov_s / 1e9) if cov_s > 0 else 0.0
         search_s = (tm["search_ms"] + tm["retry_ms"]) / 1e3
         search_gbs = (last.n_trail_steps * STEP_BYTES / search_s / 1e9) if search_s > 0 else 0.0
-        # HBM traffic per launch from the committed PMC pass of this same command (rocprofv3 cannot collect counters
-        # from inside the run): only reported when the workload is the one that pass measured
-        traffic_cov = traffic_search = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "final_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("reads_per_gpu") == a.reads:
-                traffic_cov = 1024.0 * (pmc["k_coverage"]["FETCH_SIZE_KB"] + pmc["k_coverage"]["WRITE_SIZE_KB"])
-                traffic_search = 1024.0 * (pmc["k_search"]["FETCH_SIZE_KB"] + pmc["k_search"]["WRITE_SIZE_KB"])
-        except (OSError, KeyError, ValueError):
-            pass
+        lib_hash = B.source_hash()
+        pmc = committed_pmc(lib_hash, w, n_mine)
         result = {
             "metric": "corrected long-read bases/sec (whole node); k-mer-probe HBM GB/s",
             "value": value,
@@ -157,31 +231,33 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / max(a.steps, 1),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": "config2: %d synthetic ONT-like reads/GPU (~2 kb, 12%% error), %d-entry synthetic k=%d k-mer dump "
-                            "(%d k-mers kept), table replicated per GPU" % (a.reads, len(keys), a.k, n_table),
-                "reads_per_gpu": a.reads, "k": a.k, "table_kmers": n_table,
-                "table_device_bytes": table.device_bytes, "bases_per_gpu": n_bases,
-                "read_status_hist[corrected,short,no_solid,no_structure,error]": status_hist,
-                "setup_s": setup_s,
+                "workload": w["label"],
+                "baseline_config": w["config"], "reads_total": w["reads"], "reads_rank0": n_mine, "k": w["k"],
+                "dump_entries": n_dump, "table_kmers": n_table, "junctions": bool(w["junctions"]),
+                "table_device_bytes": table.device_bytes, "bases_total": total_bases, "bases_rank0": n_bases,
+                "read_status_hist_rank0[corrected,short,no_solid,no_structure,error]": status_hist,
+                "setup_s": setup_s, "lib_source_hash": lib_hash, "gathered_reads_on_rank0": merged_reads,
             },
-            # the kernel the metric names: the k-mer coverage probe (Read::reCoverage); HBM-bound
+            # the kernel the metric names: the k-mer coverage probe (Read::reCoverage); HBM-bound.  `achieved` =
+            # algorithmic bytes (25 B per k-mer probed) / this run's launch time (HIP events on the library's stream).
+            # `traffic` = FETCH_SIZE + WRITE_SIZE of one launch from the separate rocprofv3 --pmc passes committed under
+            # profiles/ (null unless they were taken from this very build and workload): requests that leave the XCD L2s,
+            # Infinity-Cache hits included (MI355X_MICROARCH.md §HBM) — an upper bound of the HBM traffic, not HBM bytes.
             "roofline": {
                 "kernel": "k_coverage", "bound": "hbm", "achieved": cov_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": cov_gbs / HBM_PEAK_GBS, "traffic": traffic_cov,
+                "frac": cov_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_coverage"),
                 "algorithmic_bytes_per_launch": last.n_kmers * COV_BYTES_PER_KMER, "launch_ms": tm["coverage_ms"],
-                # measured bytes (PMC pass) over this run's launch time: the figure BASELINE's ">= 40 % per rocprof" refers to
-                "measured_gbs": (traffic_cov / (tm["coverage_ms"] * 1e-3) / 1e9) if (traffic_cov and tm["coverage_ms"] > 0) else None,
-                "measured_frac": (traffic_cov / (tm["coverage_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic_cov and tm["coverage_ms"] > 0) else None,
+                "traffic_note": "L2-miss (fabric) bytes per launch incl. Infinity-Cache hits, separate PMC pass; null = no pass for this build",
             },
             # the kernel that dominates the step time: the path search (integer DP + dependent probes)
             "roofline_search": {
                 "kernel": "k_search", "bound": "hbm", "achieved": search_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": search_gbs / HBM_PEAK_GBS, "traffic": traffic_search,
+                "frac": search_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_search"),
                 "algorithmic_bytes_per_launch": last.n_trail_steps * STEP_BYTES, "launch_ms": 1e3 * search_s,
                 "trail_steps": last.n_trail_steps, "dp_cells": last.n_dp_cells,
                 "dp_gcups": (last.n_dp_cells / search_s / 1e9) if search_s > 0 else 0.0,
@@ -189,8 +265,13 @@ def main():
             "kernels_ms": tm,
             "retried_reads": last.n_retried,
         }
+    if world == 1 and not a.no_h2h:
+        h2h = host_to_host(T, table, params, dev, bases, offs, max(2, a.steps), log)
+        if rank == 0:
+            result["host_to_host"] = h2h
+    if rank == 0:
         if not a.no_cpu and world == 1:
-            result["cpu_baseline"] = cpu_baseline(a, synth, keys, counts, bases, offs, out, oo, st)
+            result["cpu_baseline"] = cpu_baseline(a, w, synth, keys, counts, bases, offs, out, oo, st)
         elif not a.no_cpu:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
@@ -199,7 +280,67 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, synth, keys, counts, bases, offs, g_out, g_off, g_st):
+def committed_pmc(lib_hash, w, reads_rank):
+    """HBM-side traffic per launch from the PMC passes committed under profiles/ (rocprofv3 cannot collect counters
+    from inside this run): only when they were taken from this very build (same source hash) on this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("lib_source_hash") != lib_hash or pmc.get("baseline_config") != w["config"] or pmc.get("reads") != reads_rank:
+            return {}
+        return {k: 1024.0 * (pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) for k in ("k_coverage", "k_search") if k in pmc}
+    except (OSError, KeyError, ValueError, TypeError):
+        return {}
+
+
+def host_to_host(T, table, params, dev, bases, offs, passes, log):
+    """SURVEY §8d's phase as the reference has it — first read submitted from host memory to last corrected record back
+    in host memory (the replacement of main.cpp:247-310) — never `value`.  The workload goes through in 4 sub-batches on
+    two contexts (two host threads, one stream each, pinned staging buffers of the library), so that one sub-batch's
+    H2D / D2H copies run under the other's kernels: the streaming form the CLI uses (io.cpp:26-75 replaced)."""
+    n = len(offs) - 1
+    nsub = 4 if n >= 4000 else 1
+    cuts = [n * i // nsub for i in range(nsub + 1)]
+    subs, pins = [], []
+    for i in range(nsub):
+        lo, hi = cuts[i], cuts[i + 1]
+        nb_i = int(offs[hi]) - int(offs[lo])
+        pin_in, pin_out = T.PinnedArray(nb_i), T.PinnedArray(2 * nb_i + 4096)   # the reader's / the writer's buffers
+        pin_in.array[:] = bases[int(offs[lo]):int(offs[hi])]
+        pins += [pin_in, pin_out]
+        subs.append((pin_in.array, (offs[lo:hi + 1] - offs[lo]).copy(), pin_out.array))
+    ctxs = [T.Context(table, params, dev) for _ in range(2 if nsub > 1 else 1)]
+    outs = [None] * nsub
+
+    def worker(ci):
+        for i in range(ci, nsub, len(ctxs)):
+            outs[i] = ctxs[ci].correct(subs[i][0], subs[i][1], out=subs[i][2])
+
+    def one_pass():
+        th = [threading.Thread(target=worker, args=(ci,)) for ci in range(len(ctxs))]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    one_pass()   # warm-up: allocations, pinned staging buffers
+    times = [one_pass() for _ in range(passes)]
+    for c in ctxs:
+        c.close()
+    outs = None
+    for pa in pins:
+        pa.close()
+    dt = float(np.median(times))
+    nb = float(int(offs[n]))
+    log("host-to-host: %.1f ms per pass of %d reads (%d sub-batches on %d contexts)" % (1e3 * dt, n, nsub, len(ctxs)))
+    return {"value": nb / dt, "unit": "bases/s", "ms_per_step": 1e3 * dt, "sub_batches": nsub, "contexts": len(ctxs),
+            "what": "host buffers in -> corrected records back in host buffers (H2D + kernels + D2H, overlapped across "
+                    "two contexts); table upload and FASTA parsing/writing not included"}
+
+
+def cpu_baseline(a, w, synth, keys, counts, bases, offs, g_out, g_off, g_st):
     """The oracle (kind "port": the CPU restatement of the reference path) timed on this box's
     host cores on the first --cpu-sample reads of the same workload; also used as a parity
     spot-check of the GPU records for those reads."""
@@ -207,7 +348,7 @@ def cpu_baseline(a, synth, keys, counts, bases, offs, g_out, g_off, g_st):
     import oracle_lib as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n = min(a.cpu_sample, len(offs) - 1) if a.cpu_sample > 0 else 0
-    q = O.params(k=a.k)
+    q = O.params(k=w["k"], use_junctions=int(w["junctions"]))
     tab = O.OracleTable(q, O.OracleTable.MAP if a.cpu_backend == "map" else O.OracleTable.FLAT)
     t0 = time.time()
     if a.cpu_backend == "map":
@@ -215,6 +356,9 @@ def cpu_baseline(a, synth, keys, counts, bases, offs, g_out, g_off, g_st):
         tab.insert_packed(keys[order], counts[order], sorted_hint=True)
     else:
         tab.insert_packed(keys, counts)
+    if w["junctions"]:
+        jk, jc = synth.junction_arrays()
+        tab.colour_packed(jk, jc)
     tab.decolour()
     build_s = time.time() - t0
     if a.cpu_sample <= 0:
@@ -233,6 +377,7 @@ def cpu_baseline(a, synth, keys, counts, bases, offs, g_out, g_off, g_st):
                 and np.array_equal(o_st, g_st[:n]))
     return {
         "value": float(int(sub_off[n]) / dt), "unit": "bases/s", "cores": cores, "kind": "port",
+        "table_backend": "std::map<string,...> (the reference's, SURVEY §8d)" if a.cpu_backend == "map" else "flat open-addressed hash (faster than the reference's std::map: the ratio GPU/CPU is conservative)",
         "sample": "first %d reads of the same workload (%d bases, %.1f s wall), oracle table backend=%s built in %.0f s, "
                   "OpenMP schedule(dynamic) like main.cpp:247" % (n, int(sub_off[n]), dt, a.cpu_backend, build_s),
         "parity_with_gpu_on_sample": same,

@@ -90,6 +90,11 @@ const char* talc_last_error(void);
 int talc_params_default(talc_params* p);
 /* number of visible HIP devices (0 when there is no GPU); never initialises a device */
 int talc_device_count(void);
+/* Page-locked host memory for the buffers handed to talc_batch_create / talc_batch_fetch_corrected (replaces the
+ * StringSets of loadSeqData / outputSeqData, io.cpp:26-75): copies to and from it are DMA transfers that overlap the
+ * kernels of another context's batch.  Ordinary (pageable) buffers work everywhere too, only slower.  NULL on failure. */
+void* talc_pinned_alloc(uint64_t bytes);
+void talc_pinned_free(void* p);
 
 /* ---------------------------------------------------------------- (1) table surface ------
  * Replaces  colouredDBG buildCDBG(int, string& dump, string& junctionDump)   Jellyfish.cpp:236-295
@@ -114,8 +119,11 @@ int talc_table_from_arrays(const uint64_t* kmers, const uint32_t* counts, uint64
                            const talc_params* p, talc_table** out);
 /* The same two builders with the insert loop of buildCDBG (Jellyfish.cpp:251-269) run on GPU `device`
  * (parallel text parse on the host, CAS insertion with the first-duplicate-wins rule on the device); the
- * result is an ordinary talc_table (host image filled from the device), identical in content: every lookup
- * returns what it returns on a host-built table.  Fails with TALC_ERR_DEVICE when the GPU cannot be used. */
+ * result is an ordinary talc_table, identical in content: every lookup returns what it returns on a
+ * host-built table.  The image stays on that GPU: talc_table_colour / talc_table_decolour_repeats run there as
+ * kernels (Jellyfish.cpp:273-290: last line wins, both strands; utils.cpp:658-669), talc_table_upload to the
+ * same GPU adopts it without a copy, and a host image is only made when something needs one (host lookups, an
+ * upload to another GPU).  Fails with TALC_ERR_DEVICE when the GPU cannot be used. */
 int talc_table_build_device(const char* dump_path, const char* junction_path, const talc_params* p,
                             int device, talc_table** out, int64_t stats[3]);
 int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts, uint64_t n,
@@ -128,13 +136,25 @@ int talc_table_decolour_repeats(talc_table* t);
 uint64_t talc_table_size(const talc_table* t);        /* SR_DBG.size() (main.cpp:237) */
 /* Device memory of one uploaded copy: the two bucket tables and the presence filter, plus the walk tables
  * (2 * capacity * 64 bytes: the fast-forward's lookahead records) once an upload has built them.  An upload
- * builds them when they leave at least half of the device's free memory to the correction batches;
+ * builds them when they leave a reserve (64 GB, or a quarter of the device if that is less) to the correction batches;
  * the environment variable TALC_WALK=0 turns them off, TALC_WALK=1 makes their allocation mandatory. */
 uint64_t talc_table_device_bytes(const talc_table* t);
 
 /* Copy the table to `device` (HBM resident, replicated per GPU).  The table becomes
  * immutable.  May be called once per device. */
 int talc_table_upload(talc_table* t, int device);
+
+/* The table image of one GPU as plain bytes, for replication across the GPUs of a node (built once,
+ * sent to the peers over xGMI): two arrays of talc_table_image_bytes() bytes each (the RIGHT and the LEFT bucket
+ * table, talc_table_capacity() buckets of 32 bytes).  export copies them device-to-device into caller-owned DEVICE
+ * buffers on `device` (e.g. tensors that a RCCL broadcast then sends); import builds a table on `device` from such
+ * buffers (it copies them; the buffers stay the caller's) with the given parameters — the exporter's — and
+ * size(); the imported table is then uploaded / used like any other. */
+uint64_t talc_table_capacity(const talc_table* t);
+uint64_t talc_table_image_bytes(const talc_table* t);
+int talc_table_export_device(talc_table* t, int device, void* dst_right, void* dst_left);
+int talc_table_import_device(const talc_params* p, uint64_t capacity, uint64_t n_kmers, const void* src_right,
+                             const void* src_left, int device, talc_table** out);
 
 /* Test hooks on the uploaded table — the reference's point queries:
  *   getCount(kmer)               Jellyfish.cpp:397-413  -> (count, junction colour) or (0,0)

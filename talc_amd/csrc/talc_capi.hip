@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <numeric>
 #include <sstream>
 #include <string>
@@ -39,9 +40,37 @@ static int fail(int code, const char* fmt, ...) {
     if (_e != hipSuccess) return fail(TALC_ERR_DEVICE, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
 
+// The table lives where it was built.  A host-built table has a host image (h.right / h.left) that uploads copy; a
+// table built (or imported) on a GPU has a *staged* device image there — colouring and de-colouring run on it as
+// kernels, talc_table_upload to that same GPU adopts it without any copy, and the host image is only materialised
+// when something asks for it (host lookups, an upload to another GPU).
 struct talc_table {
   HostTable h;
+  bool hostValid = true;       // h.right / h.left hold the current table
+  int stagedDev = -1;          // GPU holding the built, not yet uploaded image (-1: none)
+  Bucket* stR = nullptr;
+  Bucket* stL = nullptr;
 };
+
+// make the host image current (device-built tables: copy it back from the GPU that holds it)
+static int ensure_host(talc_table* t) {
+  if (t->hostValid) return TALC_OK;
+  const Bucket *srcR = nullptr, *srcL = nullptr;
+  int dev = -1;
+  if (t->stagedDev >= 0) { srcR = t->stR; srcL = t->stL; dev = t->stagedDev; }
+  else if (!t->h.dev.empty()) { srcR = t->h.dev.begin()->second.right; srcL = t->h.dev.begin()->second.left; dev = t->h.dev.begin()->first; }
+  if (!srcR) return fail(TALC_ERR_STATE, "the table has neither a host image nor a device image");
+  const uint64_t bytes = t->h.capacity * sizeof(Bucket);
+  if (!t->h.right) t->h.right = (Bucket*)malloc(bytes);
+  if (!t->h.left) t->h.left = (Bucket*)malloc(bytes);
+  if (!t->h.right || !t->h.left) return fail(TALC_ERR_NOMEM, "cannot allocate the host image (%llu bytes)", (unsigned long long)(2 * bytes));
+  hipError_t e = hipSetDevice(dev);
+  if (e == hipSuccess) e = hipMemcpy(t->h.right, srcR, bytes, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(t->h.left, srcL, bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(TALC_ERR_DEVICE, "copying the table image to the host: %s", hipGetErrorString(e));
+  t->hostValid = true;
+  return TALC_OK;
+}
 
 struct Stage {
   // per-wave scratch for the search kernel
@@ -63,7 +92,50 @@ struct talc_ctx {
   Stage stage;          // default scratch
   uint32_t* d_queue = nullptr;   // work-queue counters
   uint64_t* d_counters = nullptr;  // [0]=trail steps [1]=dp cells
+  // device buffers of finished batches, kept for the next batch of this context (a streaming run creates and destroys
+  // a batch per chunk of reads: ~20 hipMalloc / hipFree pairs each time otherwise)
+  std::vector<std::pair<uint64_t, void*>> pool;   // (bytes, pointer), free
+  std::map<void*, uint64_t> live;                 // pointer -> bytes, handed out
+  uint64_t pool_bytes = 0;
 };
+
+// a device buffer of at least `bytes` from the context's cache (smallest cached one that fits and is not more than
+// twice as large), or a fresh one
+static int ctx_alloc(talc_ctx* c, void** out, uint64_t bytes) {
+  bytes = std::max<uint64_t>(bytes, 256);
+  int best = -1;
+  for (int i = 0; i < (int)c->pool.size(); ++i)
+    if (c->pool[i].first >= bytes && c->pool[i].first <= 2 * bytes + 4096 && (best < 0 || c->pool[i].first < c->pool[best].first)) best = i;
+  if (best >= 0) {
+    *out = c->pool[best].second;
+    c->live[*out] = c->pool[best].first;
+    c->pool_bytes -= c->pool[best].first;
+    c->pool.erase(c->pool.begin() + best);
+    return TALC_OK;
+  }
+  if (hipMalloc(out, bytes) != hipSuccess) {
+    // out of memory: drop the cache and try once more
+    (void)hipGetLastError();
+    for (auto& e : c->pool) hipFree(e.second);
+    c->pool.clear(); c->pool_bytes = 0;
+    HIPCHK(hipMalloc(out, bytes));
+  }
+  c->live[*out] = bytes;
+  return TALC_OK;
+}
+static void ctx_release(talc_ctx* c, void* p) {
+  if (!p) return;
+  auto it = c->live.find(p);
+  if (it == c->live.end()) { hipFree(p); return; }
+  c->pool.push_back({it->second, p});
+  c->pool_bytes += it->second;
+  c->live.erase(it);
+  while (c->pool.size() > 64) {   // a bounded cache: drop the oldest entries beyond 64 buffers
+    c->pool_bytes -= c->pool.front().first;
+    hipFree(c->pool.front().second);
+    c->pool.erase(c->pool.begin());
+  }
+}
 
 struct talc_batch {
   talc_ctx* ctx = nullptr;
@@ -97,10 +169,12 @@ struct talc_batch {
   uint64_t* d_dense_off = nullptr;
 };
 
+static int ctx_alloc(talc_ctx* c, void** out, uint64_t bytes);
 template <typename T>
-static int up(T** d, const std::vector<T>& h, hipStream_t s) {
+static int up(talc_ctx* c, T** d, const std::vector<T>& h, hipStream_t s) {
   size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
-  HIPCHK(hipMalloc((void**)d, bytes));
+  int rc_ = ctx_alloc(c, (void**)d, bytes);
+  if (rc_) return rc_;
   if (!h.empty()) HIPCHK(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   return TALC_OK;
 }
@@ -125,6 +199,14 @@ int talc_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
+
+// page-locked host memory for read / record buffers: copies to and from it are DMA transfers that run beside kernels
+void* talc_pinned_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, std::max<uint64_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail(TALC_ERR_NOMEM, "cannot allocate %llu bytes of pinned host memory", (unsigned long long)bytes); return nullptr; }
+  return p;
+}
+void talc_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
 
 static int check_params(const talc_params* p) {
   if (!p) return fail(TALC_ERR_INVALID, "null params");
@@ -156,8 +238,7 @@ int talc_table_from_arrays(const uint64_t* kmers, const uint32_t* counts, uint64
   return TALC_OK;
 }
 
-// the table built on `device` (talc_kernels_build.h), then copied back so that the object is a complete talc_table
-// (host lookups, colouring, upload to any device)
+// the table built on `device` (talc_kernels_build.h); the image stays there (staged) until talc_table_upload adopts it
 int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts, uint64_t n, const talc_params* p, int device,
                                   talc_table** out) {
   int rc = check_params(p);
@@ -169,13 +250,15 @@ int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts,
   for (long i = 0; i < (long)n; ++i) kept += counts[i] >= p->min_count ? 1 : 0;
   talc_table* t = new talc_table();
   t->h.p = *p;
-  if (!t->h.allocate(kept, false)) { delete t; return fail(TALC_ERR_NOMEM, "cannot allocate host table for %llu k-mers", (unsigned long long)kept); }
+  t->h.capacity = kept * 2 + 64;   // load factor <= 0.5 (HostTable::allocate)
+  if (t->h.capacity >= (1ULL << 32)) { delete t; return fail(TALC_ERR_NOMEM, "table of %llu k-mers exceeds 2^32 buckets", (unsigned long long)kept); }
+  t->hostValid = false;
   const uint64_t cap = t->h.capacity, bytes = cap * sizeof(Bucket);
   Bucket *dR = nullptr, *dL = nullptr;
   uint64_t* dK = nullptr; uint32_t *dC = nullptr, *dSR = nullptr, *dSL = nullptr;
   unsigned long long* dStats = nullptr;
-  auto cleanup = [&]() { hipFree(dR); hipFree(dL); hipFree(dK); hipFree(dC); hipFree(dSR); hipFree(dSL); hipFree(dStats); };
-#define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); delete t; return fail(TALC_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  auto cleanup = [&]() { hipFree(dK); hipFree(dC); hipFree(dSR); hipFree(dSL); hipFree(dStats); };
+#define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); hipFree(dR); hipFree(dL); delete t; return fail(TALC_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
   BCHK(hipSetDevice(device));
   BCHK(hipMalloc((void**)&dR, bytes)); BCHK(hipMalloc((void**)&dL, bytes));
   BCHK(hipMalloc((void**)&dK, std::max<uint64_t>(n, 1) * 8)); BCHK(hipMalloc((void**)&dC, std::max<uint64_t>(n, 1) * 4));
@@ -195,12 +278,46 @@ int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts,
   BCHK(hipDeviceSynchronize());
   unsigned long long st[3];
   BCHK(hipMemcpy(st, dStats, 3 * 8, hipMemcpyDeviceToHost));
-  BCHK(hipMemcpy(t->h.right, dR, bytes, hipMemcpyDeviceToHost));
-  BCHK(hipMemcpy(t->h.left, dL, bytes, hipMemcpyDeviceToHost));
 #undef BCHK
   cleanup();
+  t->stagedDev = device; t->stR = dR; t->stL = dL;
   t->h.nkmers = st[0]; t->h.nbuckets_right = st[1]; t->h.nbuckets_left = st[2];
   *out = t;
+  return TALC_OK;
+}
+
+// Junction colouring (Jellyfish.cpp:273-290) on the staged device image: last line wins, both strands.
+static int colour_on_device(talc_table* t, const uint64_t* jkmers, const int64_t* jcounts, uint64_t n) {
+  if (n == 0) return TALC_OK;
+  if (n >= (1ull << 31)) return fail(TALC_ERR_INVALID, "the device colouring takes fewer than 2^31 junction lines");
+  HIPCHK(hipSetDevice(t->stagedDev));
+  uint64_t hsize = 1024;
+  while (hsize < 4 * n) hsize *= 2;   // two bids per line at most: load <= 0.5
+  uint64_t *dJ = nullptr, *dIds = nullptr; int64_t* dC = nullptr; unsigned long long* dHK = nullptr; uint32_t* dHS = nullptr;
+  auto cleanup = [&]() { hipFree(dJ); hipFree(dC); hipFree(dIds); hipFree(dHK); hipFree(dHS); };
+#define CCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(TALC_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  CCHK(hipMalloc((void**)&dJ, n * 8)); CCHK(hipMalloc((void**)&dC, n * 8)); CCHK(hipMalloc((void**)&dIds, 2 * n * 8));
+  CCHK(hipMalloc((void**)&dHK, hsize * 8)); CCHK(hipMalloc((void**)&dHS, hsize * 4));
+  CCHK(hipMemcpy(dJ, jkmers, n * 8, hipMemcpyHostToDevice)); CCHK(hipMemcpy(dC, jcounts, n * 8, hipMemcpyHostToDevice));
+  CCHK(hipMemset(dHK, 0xFF, hsize * 8)); CCHK(hipMemset(dHS, 0, hsize * 4));
+  const unsigned nb = (unsigned)((2 * n + 255) / 256);
+  hipLaunchKernelGGL(k_colour_claim, dim3(nb), dim3(256), 0, 0, t->stR, t->h.capacity, t->h.p.k, dJ, dC, n, t->h.p.coloured_count_thr,
+                     dIds, dHK, dHS, hsize - 1);
+  hipLaunchKernelGGL(k_colour_write, dim3(nb), dim3(256), 0, 0, t->stR, t->stL, t->h.capacity, t->h.p.k, dJ, dC, n, dIds, dHK, dHS,
+                     hsize - 1);
+  CCHK(hipGetLastError());
+  CCHK(hipDeviceSynchronize());
+#undef CCHK
+  cleanup();
+  t->hostValid = false;
+  return TALC_OK;
+}
+static int decolour_on_device(talc_table* t) {
+  HIPCHK(hipSetDevice(t->stagedDev));
+  hipLaunchKernelGGL(k_decolour_repeats, dim3(1), dim3(64), 0, 0, t->stR, t->stL, t->h.capacity, t->h.p.k);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  t->hostValid = false;
   return TALC_OK;
 }
 
@@ -226,9 +343,9 @@ static int table_build_impl(const char* dump_path, const char* junction_path, co
     DumpStats js;
     if (!parseDumpFile(junction_path, p->k, 0, false, jk, nullptr, &jc, js)) { delete t; return fail(TALC_ERR_IO, "cannot open %s", junction_path); }
     ds.nbad += js.nbad;
-    t->h.colour(jk.data(), jc.data(), jk.size());
+    if ((rc = talc_table_colour(t, jk.data(), jc.data(), jk.size()))) { talc_table_destroy(t); return rc; }
   }
-  t->h.decolourRepeats();  // main.cpp:232
+  if ((rc = talc_table_decolour_repeats(t))) { talc_table_destroy(t); return rc; }  // main.cpp:232
   if (stats) { stats[0] = ds.nread; stats[1] = ds.nkept; stats[2] = ds.nbad; }
   *out = t;
   return TALC_OK;
@@ -247,12 +364,14 @@ int talc_table_build_device(const char* dump_path, const char* junction_path, co
 int talc_table_colour(talc_table* t, const uint64_t* jkmers, const int64_t* jcounts, uint64_t n) {
   if (!t || (n && (!jkmers || !jcounts))) return fail(TALC_ERR_INVALID, "null argument");
   if (t->h.frozen) return fail(TALC_ERR_STATE, "table already uploaded (immutable)");
+  if (t->stagedDev >= 0) return colour_on_device(t, jkmers, jcounts, n);
   t->h.colour(jkmers, jcounts, n);
   return TALC_OK;
 }
 int talc_table_decolour_repeats(talc_table* t) {
   if (!t) return fail(TALC_ERR_INVALID, "null argument");
   if (t->h.frozen) return fail(TALC_ERR_STATE, "table already uploaded (immutable)");
+  if (t->stagedDev >= 0) return decolour_on_device(t);
   t->h.decolourRepeats();
   return TALC_OK;
 }
@@ -268,28 +387,41 @@ uint64_t talc_table_device_bytes(const talc_table* t) {
 int talc_table_upload(talc_table* t, int device) {
   if (!t) return fail(TALC_ERR_INVALID, "null table");
   if (t->h.dev.count(device)) return TALC_OK;
-  if (!t->h.right) return fail(TALC_ERR_STATE, "host image already released");
-  HIPCHK(hipSetDevice(device));
   DeviceCopy dc;
   const uint64_t bytes = t->h.capacity * sizeof(Bucket);
-  HIPCHK(hipMalloc((void**)&dc.right, bytes));
-  HIPCHK(hipMalloc((void**)&dc.left, bytes));
-  HIPCHK(hipMemcpy(dc.right, t->h.right, bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dc.left, t->h.left, bytes, hipMemcpyHostToDevice));
-  {
-    const std::vector<uint64_t> f = t->h.buildFilter();
-    dc.filterWords = f.size();
-    HIPCHK(hipMalloc((void**)&dc.filter, f.size() * 8));
-    HIPCHK(hipMemcpy(dc.filter, f.data(), f.size() * 8, hipMemcpyHostToDevice));
+  if (t->stagedDev == device) {   // built (or imported) on this GPU: the image is adopted as it stands
+    HIPCHK(hipSetDevice(device));
+    dc.right = t->stR; dc.left = t->stL;
+    t->stR = t->stL = nullptr; t->stagedDev = -1;
+  } else {
+    int rc = ensure_host(t);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMalloc((void**)&dc.right, bytes));
+    HIPCHK(hipMalloc((void**)&dc.left, bytes));
+    HIPCHK(hipMemcpy(dc.right, t->h.right, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc.left, t->h.left, bytes, hipMemcpyHostToDevice));
   }
-  // walk tables (WalkEntry, talc_common.h): twice the bucket tables' size again, so only when that leaves at least
-  // half of the device's free memory to the correction batches; TALC_WALK=0 turns them off, TALC_WALK=1 insists
+  {   // presence filter, from the RIGHT table
+    dc.filterWords = std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64);
+    HIPCHK(hipMalloc((void**)&dc.filter, dc.filterWords * 8));
+    HIPCHK(hipMemset(dc.filter, 0, dc.filterWords * 8));
+    if (t->h.capacity)
+      hipLaunchKernelGGL(k_build_filter, dim3((unsigned)((t->h.capacity + 255) / 256)), dim3(256), 0, 0, dc.right, t->h.capacity,
+                         (unsigned long long*)dc.filter, dc.filterWords);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+  }
+  // walk tables (WalkEntry, talc_common.h): twice the bucket tables' size again, so only when that leaves the
+  // correction batches and their scratch a reserve (64 GB, or a quarter of the device if that is less: two contexts
+  // with 200 k-read batches of config 5 need about that); TALC_WALK=0 turns them off, TALC_WALK=1 insists
   {
     const char* env = getenv("TALC_WALK");
     const uint64_t wbytes = t->h.capacity * sizeof(WalkEntry);
     size_t freeB = 0, totalB = 0;
     HIPCHK(hipMemGetInfo(&freeB, &totalB));
-    const bool want = env ? atoi(env) != 0 : (2 * wbytes <= freeB / 2);
+    const uint64_t reserve = std::min<uint64_t>(64ull << 30, (uint64_t)totalB / 4);
+    const bool want = env ? atoi(env) != 0 : ((uint64_t)freeB >= 2 * wbytes + reserve);
     if (want && t->h.capacity) {
       if (hipMalloc((void**)&dc.walkRight, wbytes) != hipSuccess || hipMalloc((void**)&dc.walkLeft, wbytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -306,6 +438,46 @@ int talc_table_upload(talc_table* t, int device) {
   }
   t->h.dev[device] = dc;
   t->h.frozen = true;
+  return TALC_OK;
+}
+
+// ---- the device image as plain bytes (replication across the GPUs of a node: rank 0 builds, the image travels over
+// RCCL / xGMI in caller-owned device buffers, every other rank imports it)
+uint64_t talc_table_capacity(const talc_table* t) { return t ? t->h.capacity : 0; }
+uint64_t talc_table_image_bytes(const talc_table* t) { return t ? t->h.capacity * sizeof(Bucket) : 0; }
+
+int talc_table_export_device(talc_table* t, int device, void* dst_right, void* dst_left) {
+  if (!t || !dst_right || !dst_left) return fail(TALC_ERR_INVALID, "null argument");
+  const Bucket *srcR = nullptr, *srcL = nullptr;
+  auto it = t->h.dev.find(device);
+  if (it != t->h.dev.end()) { srcR = it->second.right; srcL = it->second.left; }
+  else if (t->stagedDev == device) { srcR = t->stR; srcL = t->stL; }
+  else return fail(TALC_ERR_STATE, "the table has no image on device %d", device);
+  HIPCHK(hipSetDevice(device));
+  const uint64_t bytes = t->h.capacity * sizeof(Bucket);
+  HIPCHK(hipMemcpy(dst_right, srcR, bytes, hipMemcpyDeviceToDevice));
+  HIPCHK(hipMemcpy(dst_left, srcL, bytes, hipMemcpyDeviceToDevice));
+  HIPCHK(hipDeviceSynchronize());
+  return TALC_OK;
+}
+
+int talc_table_import_device(const talc_params* p, uint64_t capacity, uint64_t n_kmers, const void* src_right, const void* src_left,
+                             int device, talc_table** out) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!out || !src_right || !src_left || capacity == 0 || capacity >= (1ULL << 32)) return fail(TALC_ERR_INVALID, "bad argument");
+  talc_table* t = new talc_table();
+  t->h.p = *p; t->h.capacity = capacity; t->h.nkmers = n_kmers; t->hostValid = false;
+  const uint64_t bytes = capacity * sizeof(Bucket);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->stR, bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->stL, bytes);
+  if (e == hipSuccess) e = hipMemcpy(t->stR, src_right, bytes, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->stL, src_left, bytes, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { hipFree(t->stR); hipFree(t->stL); delete t; return fail(TALC_ERR_DEVICE, "importing the table image: %s", hipGetErrorString(e)); }
+  t->stagedDev = device;
+  *out = t;
   return TALC_OK;
 }
 
@@ -359,8 +531,10 @@ int talc_table_next_counts_batch(talc_table* t, int device, const uint64_t* kmer
 int talc_table_lookup_host_batch(const talc_table* t, const uint64_t* kmers, uint64_t n, uint32_t* counts,
                                  uint32_t* jcounts) {
   if (!t || (n && (!kmers || !counts || !jcounts))) return fail(TALC_ERR_INVALID, "null argument");
-  if (!t->h.right) return fail(TALC_ERR_STATE, "host image released");
-  for (uint64_t i = 0; i < n; ++i) t->h.lookup(kmers[i], counts[i], jcounts[i]);
+  int rc = ensure_host(const_cast<talc_table*>(t));   // (a device-built table: the image is copied back on first use)
+  if (rc) return rc;
+#pragma omp parallel for schedule(static) if (n > 100000)
+  for (long i = 0; i < (long)n; ++i) t->h.lookup(kmers[i], counts[i], jcounts[i]);
   return TALC_OK;
 }
 
@@ -370,6 +544,7 @@ void talc_table_destroy(talc_table* t) {
     if (hipSetDevice(kv.first) == hipSuccess) { hipFree(kv.second.right); hipFree(kv.second.left); hipFree(kv.second.filter);
       hipFree(kv.second.walkRight); hipFree(kv.second.walkLeft); }
   }
+  if (t->stagedDev >= 0 && hipSetDevice(t->stagedDev) == hipSuccess) { hipFree(t->stR); hipFree(t->stL); }
   delete t;
 }
 
@@ -409,6 +584,8 @@ void talc_ctx_destroy(talc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   free_stage(c->stage);
+  for (auto& e : c->pool) hipFree(e.second);
+  for (auto& e : c->live) hipFree(e.first);   // (batches that outlived their context: their memory goes with it)
   if (c->d_queue) hipFree(c->d_queue);
   if (c->d_counters) hipFree(c->d_counters);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
@@ -429,7 +606,7 @@ void talc_batch_destroy(talc_batch* b) {
   void* ptrs[] = {b->d_raw, b->d_codes, b->d_offsets, b->d_koff, b->d_tile_read, b->d_tile_start, b->d_chunk_read,
                   b->d_chunk_start, b->d_order, b->d_cov, b->d_nin, b->d_state, b->d_regions, b->d_regoff, b->d_out, b->d_outoff,
                   b->d_dense, b->d_dense_off};
-  for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : ptrs) if (p) ctx_release(b->ctx, p);
   delete b;
 }
 
@@ -468,23 +645,23 @@ int talc_batch_create(talc_ctx* c, const char* bases, const uint64_t* offsets, u
   });
   hipStream_t s = c->stream;
   int rc;
-  HIPCHK(hipMalloc((void**)&b->d_raw, std::max<uint64_t>(b->n_bases, 1)));
-  HIPCHK(hipMalloc((void**)&b->d_codes, std::max<uint64_t>(b->n_bases, 1)));
+  if ((rc = ctx_alloc(c, (void**)&b->d_raw, std::max<uint64_t>(b->n_bases, 1)))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_codes, std::max<uint64_t>(b->n_bases, 1)))) return rc;
   if (b->n_bases) HIPCHK(hipMemcpyAsync(b->d_raw, bases, b->n_bases, hipMemcpyHostToDevice, s));
-  if ((rc = up(&b->d_offsets, b->h_offsets, s))) return rc;
-  if ((rc = up(&b->d_koff, b->h_koff, s))) return rc;
-  if ((rc = up(&b->d_regoff, b->h_regoff, s))) return rc;
-  if ((rc = up(&b->d_outoff, b->h_outoff, s))) return rc;
-  if ((rc = up(&b->d_tile_read, b->h_tile_read, s))) return rc;
-  if ((rc = up(&b->d_tile_start, b->h_tile_start, s))) return rc;
-  if ((rc = up(&b->d_chunk_read, b->h_chunk_read, s))) return rc;
-  if ((rc = up(&b->d_chunk_start, b->h_chunk_start, s))) return rc;
-  if ((rc = up(&b->d_order, b->h_order, s))) return rc;
-  HIPCHK(hipMalloc((void**)&b->d_cov, std::max<uint64_t>(b->n_kmers, 1) * sizeof(uint2)));
-  HIPCHK(hipMalloc((void**)&b->d_nin, std::max<uint32_t>(n_reads, 1) * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&b->d_state, std::max<uint32_t>(n_reads, 1) * sizeof(ReadState)));
-  HIPCHK(hipMalloc((void**)&b->d_regions, std::max<uint64_t>(ro, 1) * 2 * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&b->d_out, std::max<uint64_t>(oo, 1)));
+  if ((rc = up(c, &b->d_offsets, b->h_offsets, s))) return rc;
+  if ((rc = up(c, &b->d_koff, b->h_koff, s))) return rc;
+  if ((rc = up(c, &b->d_regoff, b->h_regoff, s))) return rc;
+  if ((rc = up(c, &b->d_outoff, b->h_outoff, s))) return rc;
+  if ((rc = up(c, &b->d_tile_read, b->h_tile_read, s))) return rc;
+  if ((rc = up(c, &b->d_tile_start, b->h_tile_start, s))) return rc;
+  if ((rc = up(c, &b->d_chunk_read, b->h_chunk_read, s))) return rc;
+  if ((rc = up(c, &b->d_chunk_start, b->h_chunk_start, s))) return rc;
+  if ((rc = up(c, &b->d_order, b->h_order, s))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_cov, std::max<uint64_t>(b->n_kmers, 1) * sizeof(uint2)))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_nin, std::max<uint32_t>(n_reads, 1) * sizeof(int32_t)))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_state, std::max<uint32_t>(n_reads, 1) * sizeof(ReadState)))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_regions, std::max<uint64_t>(ro, 1) * 2 * sizeof(uint32_t)))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_out, std::max<uint64_t>(oo, 1)))) return rc;
   HIPCHK(hipStreamSynchronize(s));
   *out = b;
   return TALC_OK;

@@ -98,6 +98,107 @@ __global__ void k_build_finalize(Bucket* right, Bucket* left, uint64_t cap, unsi
   if (threadIdx.x == 0) { if (s[0]) atomicAdd(&stats[0], s[0]); if (s[1]) atomicAdd(&stats[1], s[1]); if (s[2]) atomicAdd(&stats[2], s[2]); }
 }
 
+// ------------------------------------------------------------------ junction colours on the device (Jellyfish.cpp:273-290)
+// The reference walks the junction dump line by line and, for the k-mer and then for its reverse complement, sets the
+// colour if the junction count is below colouredCountThr and the k-mer is in the table (:278-289) — so when several
+// lines reach the same k-mer the LAST one in (line, strand) order wins.  Entry e = 2 * line + strand.  Three passes:
+//   claim   every entry that passes the threshold and finds its k-mer bids for it with atomicMax(e + 1) in a scratch
+//           hash keyed by the k-mer's count slot (RIGHT bucket index * 4 + last base);
+//   write   the entry whose bid is the one left there stores its colour in both tables.
+// (16-bit stores: the four colours of a bucket share two dwords, byte-enabled writes do not disturb their neighbours.)
+TALC_D uint64_t dev_revcomp(uint64_t km, uint32_t K) {
+  // complement = 3 - base = bitwise not of the 2-bit code; then reverse the 2-bit groups of the K-mer
+  uint64_t x = ~km;
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  x = __builtin_bswap64(x);
+  return x >> (64 - 2 * K);
+}
+// slot of `key` in tab, or ~0 if absent
+TALC_D uint64_t dev_find_slot(const Bucket* tab, uint64_t cap, uint64_t key) {
+  uint64_t i = table_home(key, cap);
+  while (true) {
+    const uint64_t k = ((const uint64_t TALC_AS1*)&tab[i].key)[0];
+    if (k == key) return i;
+    if (k == kEmptyKey) return ~0ULL;
+    if (++i == cap) i = 0;
+  }
+}
+static constexpr uint64_t kNoId = ~0ULL;
+
+__global__ void k_colour_claim(const Bucket* __restrict__ right, uint64_t cap, uint32_t K, const uint64_t* __restrict__ jk,
+                               const int64_t* __restrict__ jc, uint64_t n, uint32_t thr, uint64_t* __restrict__ ids,
+                               unsigned long long* __restrict__ hkeys, uint32_t* __restrict__ hseq, uint64_t hmask) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * n) return;
+  const uint64_t i = e >> 1;
+  uint64_t id = kNoId;
+  if ((unsigned int)(int)jc[i] < thr) {   // Jellyfish.cpp:284: int compared with unsigned
+    const uint64_t km = (e & 1) ? dev_revcomp(jk[i], K) : jk[i];
+    const uint64_t sr = dev_find_slot(right, cap, km >> 2);
+    if (sr != ~0ULL && right[sr].cnt[km & 3] != 0) id = sr * 4 + (km & 3);
+  }
+  ids[e] = id;
+  if (id == kNoId) return;
+  uint64_t h = mix64(id) & hmask;
+  while (true) {
+    unsigned long long cur = __atomic_load_n(&hkeys[h], __ATOMIC_RELAXED);
+    if (cur == kNoId) { const unsigned long long old = atomicCAS(&hkeys[h], (unsigned long long)kNoId, (unsigned long long)id); cur = (old == kNoId) ? id : old; }
+    if (cur == id) break;
+    h = (h + 1) & hmask;
+  }
+  atomicMax(&hseq[h], (uint32_t)(e + 1));
+}
+
+__global__ void k_colour_write(Bucket* __restrict__ right, Bucket* __restrict__ left, uint64_t cap, uint32_t K,
+                               const uint64_t* __restrict__ jk, const int64_t* __restrict__ jc, uint64_t n,
+                               const uint64_t* __restrict__ ids, const unsigned long long* __restrict__ hkeys,
+                               const uint32_t* __restrict__ hseq, uint64_t hmask) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * n) return;
+  const uint64_t id = ids[e];
+  if (id == kNoId) return;
+  uint64_t h = mix64(id) & hmask;
+  while (hkeys[h] != id) h = (h + 1) & hmask;
+  if (hseq[h] != (uint32_t)(e + 1)) return;   // a later line colours this k-mer
+  const uint64_t i = e >> 1;
+  const uint64_t km = (e & 1) ? dev_revcomp(jk[i], K) : jk[i];
+  const uint16_t c = (uint16_t)(int)jc[i];
+  right[id >> 2].jc[id & 3] = c;
+  const uint64_t m1 = (1ULL << (2 * (K - 1))) - 1;
+  const uint64_t sl = dev_find_slot(left, cap, km & m1);
+  const uint32_t fb = (uint32_t)((km >> (2 * (K - 1))) & 3);
+  if (sl != ~0ULL && left[sl].cnt[fb] != 0) left[sl].jc[fb] = c;
+}
+
+// decolourRepeatsFromDBG (utils.cpp:658-669): the colour of the four homopolymer k-mers becomes 0
+__global__ void k_decolour_repeats(Bucket* __restrict__ right, Bucket* __restrict__ left, uint64_t cap, uint32_t K) {
+  const uint32_t b = threadIdx.x;
+  if (b >= 4) return;
+  uint64_t km = 0;
+  for (uint32_t i = 0; i < K; ++i) km = (km << 2) | b;
+  const uint64_t m1 = (1ULL << (2 * (K - 1))) - 1;
+  const uint64_t sr = dev_find_slot(right, cap, km >> 2);
+  if (sr != ~0ULL && right[sr].cnt[b] != 0) right[sr].jc[b] = 0;
+  const uint64_t sl = dev_find_slot(left, cap, km & m1);
+  if (sl != ~0ULL && left[sl].cnt[b] != 0) left[sl].jc[b] = 0;
+}
+
+// presence filter (TableView::filter) from the RIGHT table, one thread per bucket
+__global__ void k_build_filter(const Bucket* __restrict__ right, uint64_t cap, unsigned long long* __restrict__ filter,
+                               uint64_t nWords) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cap) return;
+  const BucketRegs r = load_bucket(right + j);
+  if (r.key == kEmptyKey) return;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (r.cnt[b] == 0) continue;
+    const uint64_t h = filter_hash((r.key << 2) | (uint64_t)b);
+    atomicOr(&filter[__umul64hi(h, nWords)], (unsigned long long)filter_mask(h));
+  }
+}
+
 // ------------------------------------------------------------------ walk tables (WalkEntry, talc_common.h)
 // One thread per bucket of either table: level 0 from the bucket's own counts, then up to WALK_LEVELS-1 dependent
 // probes along the largest-count successor.  Runs once per upload.

@@ -139,25 +139,6 @@ struct HostTable {
     }
   }
 
-  // presence filter over the stored K-mers (TableView::filter), built from the RIGHT table
-  static inline uint64_t filterWordIndex(uint64_t h, uint64_t nWords) {
-    return (uint64_t)(((unsigned __int128)h * (unsigned __int128)nWords) >> 64);
-  }
-  std::vector<uint64_t> buildFilter() const {
-    const uint64_t nWords = std::max<uint64_t>(64, (nkmers * 10 + 63) / 64);
-    std::vector<uint64_t> w(nWords, 0);
-#pragma omp parallel for schedule(static)
-    for (long i = 0; i < (long)capacity; ++i) {
-      if (right[i].key == kEmptyKey) continue;
-      for (int b = 0; b < 4; ++b) {
-        if (right[i].cnt[b] == 0) continue;
-        const uint64_t h = filter_hash((right[i].key << 2) | (uint64_t)b);
-        __atomic_fetch_or(&w[filterWordIndex(h, nWords)], filter_mask(h), __ATOMIC_RELAXED);
-      }
-    }
-    return w;
-  }
-
   // (count, colour) of a full k-mer, host side
   bool lookup(uint64_t km, uint32_t& cnt, uint32_t& jc) const {
     const Bucket* b = find(right, capacity, km >> 2);

@@ -20,10 +20,11 @@ LOG_MESSAGES = {
 
 # every symbol include/talc_hip.h declares
 ABI_SYMBOLS = [
-    "talc_abi_version", "talc_last_error", "talc_params_default", "talc_device_count",
+    "talc_abi_version", "talc_last_error", "talc_params_default", "talc_device_count", "talc_pinned_alloc", "talc_pinned_free",
     "talc_table_build", "talc_table_from_arrays", "talc_table_build_device", "talc_table_from_arrays_device",
     "talc_table_colour", "talc_table_decolour_repeats",
-    "talc_table_size", "talc_table_device_bytes", "talc_table_upload", "talc_table_lookup_batch",
+    "talc_table_size", "talc_table_device_bytes", "talc_table_upload", "talc_table_capacity", "talc_table_image_bytes",
+    "talc_table_export_device", "talc_table_import_device", "talc_table_lookup_batch",
     "talc_table_next_counts_batch", "talc_table_lookup_host_batch", "talc_table_destroy",
     "talc_ctx_create", "talc_ctx_destroy", "talc_batch_create", "talc_batch_destroy",
     "talc_batch_coverage", "talc_batch_fetch_coverage", "talc_batch_num_kmers", "talc_batch_num_bases",
@@ -99,6 +100,9 @@ def lib():
         vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
         L.talc_last_error.restype = C.c_char_p
         L.talc_params_default.argtypes = [C.POINTER(Params)]
+        L.talc_pinned_alloc.restype = vp
+        L.talc_pinned_alloc.argtypes = [u64]
+        L.talc_pinned_free.argtypes = [vp]
         L.talc_table_build.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Params), C.POINTER(vp), vp]
         L.talc_table_from_arrays.argtypes = [vp, vp, u64, C.POINTER(Params), C.POINTER(vp)]
         L.talc_table_build_device.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Params), i32, C.POINTER(vp), vp]
@@ -110,6 +114,12 @@ def lib():
         L.talc_table_device_bytes.restype = u64
         L.talc_table_device_bytes.argtypes = [vp]
         L.talc_table_upload.argtypes = [vp, i32]
+        L.talc_table_capacity.restype = u64
+        L.talc_table_capacity.argtypes = [vp]
+        L.talc_table_image_bytes.restype = u64
+        L.talc_table_image_bytes.argtypes = [vp]
+        L.talc_table_export_device.argtypes = [vp, i32, vp, vp]
+        L.talc_table_import_device.argtypes = [C.POINTER(Params), u64, u64, vp, vp, i32, C.POINTER(vp)]
         L.talc_table_lookup_batch.argtypes = [vp, i32, vp, u64, vp, vp]
         L.talc_table_next_counts_batch.argtypes = [vp, i32, vp, u64, i32, vp, vp]
         L.talc_table_lookup_host_batch.argtypes = [vp, vp, u64, vp, vp]
@@ -162,6 +172,29 @@ def device_count():
     return int(lib().talc_device_count())
 
 
+class PinnedArray:
+    """A uint8 numpy view over page-locked host memory of the library (talc_pinned_alloc)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self._p = lib().talc_pinned_alloc(max(self.nbytes, 1))
+        if not self._p:
+            raise TalcError("talc_pinned_alloc(%d) failed: %s" % (nbytes, lib().talc_last_error().decode(errors="replace")))
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self._p))[: self.nbytes]
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().talc_pinned_free(C.c_void_p(self._p))
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Table:
     """The SR k-mer table (replaces buildCDBG, Jellyfish.cpp:236-295)."""
 
@@ -212,6 +245,27 @@ class Table:
 
     def upload(self, device=0):
         _chk(lib().talc_table_upload(self._h, device))
+
+    @property
+    def capacity(self):
+        return int(lib().talc_table_capacity(self._h))
+
+    @property
+    def image_bytes(self):
+        """Bytes of each of the two bucket tables (RIGHT, LEFT) of the device image."""
+        return int(lib().talc_table_image_bytes(self._h))
+
+    def export_device(self, device, ptr_right, ptr_left):
+        """Copy the image on `device` into two caller-owned device buffers of image_bytes each."""
+        _chk(lib().talc_table_export_device(self._h, int(device), C.c_void_p(ptr_right), C.c_void_p(ptr_left)))
+
+    @classmethod
+    def import_device(cls, params, capacity, n_kmers, ptr_right, ptr_left, device):
+        """A table on `device` from an exported image (two device buffers; they are copied)."""
+        h = C.c_void_p()
+        _chk(lib().talc_table_import_device(C.byref(params), int(capacity), int(n_kmers), C.c_void_p(ptr_right),
+                                            C.c_void_p(ptr_left), int(device), C.byref(h)))
+        return cls(h, params)
 
     def lookup(self, kmers, device=0):
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
@@ -270,12 +324,12 @@ class Context:
         _chk(lib().talc_test_dp(self._h, mode, a, len(a), b, len(b), p0, p1, p2, p3, out.ctypes.data))
         return out
 
-    def correct(self, bases, offsets):
+    def correct(self, bases, offsets, out=None):
         """One-shot: returns (out uint8 ASCII, out_offsets, status)."""
         b = self.batch(bases, offsets)
         try:
             b.correct()
-            return b.fetch_corrected()
+            return b.fetch_corrected(out)
         finally:
             b.close()
 
@@ -327,9 +381,11 @@ class Batch:
         """0, or WARN_READ_ERRORS when some reads exhausted the device scratch (status READ_ERROR, passed through)."""
         return _chk(lib().talc_batch_correct(self.ctx._h, self._h))
 
-    def fetch_corrected(self):
+    def fetch_corrected(self, out=None):
+        """(records uint8 ASCII, offsets, status); `out`: a caller's uint8 buffer to fill (e.g. PinnedArray.array)."""
         total = int(lib().talc_batch_corrected_bytes(self._h))
-        out = np.empty(max(total, 1), dtype=np.uint8)
+        if out is None or len(out) < total:
+            out = np.empty(max(total, 1), dtype=np.uint8)
         oo = np.empty(self.n_reads + 1, dtype=np.uint64)
         st = np.empty(self.n_reads, dtype=np.int32)
         _chk(lib().talc_batch_fetch_corrected(self.ctx._h, self._h, out.ctypes.data, total, oo.ctypes.data, st.ctypes.data))

@@ -57,6 +57,17 @@ def pack_records(seq_bytes, offsets, status):
                          + np.asarray(status, dtype=np.int32).tobytes() + bytes(seq_bytes), dtype=np.uint8)
 
 
+def pack_records_device(torch, records, offsets, status):
+    """The same payload assembled on the device: `records` is a uint8 device tensor (the dense corrected records of
+    talc_batch_copy_corrected_device), offsets / status the host arrays that call returned.  One small H2D copy for the
+    header; the records never leave the GPU."""
+    n = len(status)
+    head = np.concatenate([np.array([n], dtype=np.uint64).view(np.uint8),
+                           np.ascontiguousarray(offsets, dtype=np.uint64).view(np.uint8),
+                           np.ascontiguousarray(status, dtype=np.int32).view(np.uint8)])
+    return torch.cat([torch.from_numpy(head).to(records.device), records])
+
+
 def unpack_records(buf):
     b = bytes(buf)
     n = int(np.frombuffer(b[:8], dtype=np.uint64)[0])

@@ -113,6 +113,12 @@ class Synth:
         L.synth_reads(self._h, first, n, bases.ctypes.data, offsets.ctypes.data)
         return bases, offsets
 
+    def read_lengths(self, first, n):
+        """Lengths (int64[n]) of reads [first, first+n) without materialising them."""
+        offsets = np.empty(n + 1, dtype=np.uint64)
+        lib().synth_reads(self._h, first, n, None, offsets.ctypes.data)
+        return np.diff(offsets.astype(np.int64))
+
     def write_dump(self, path):
         if lib().synth_write_dump(self._h, path.encode()) != 0:
             raise IOError(path)

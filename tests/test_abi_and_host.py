@@ -161,3 +161,25 @@ def test_synth_is_deterministic_and_sharded():
     assert (ca == 1).sum() > 0 and (ca >= 2).sum() > 30_000
     lens = np.diff(oa.astype(np.int64))
     assert lens.max() < 6000 and lens.mean() > 500
+
+
+def test_bench_workload_is_derived_from_its_arguments():
+    """bench.py names the workload it really ran: N = 1 is BASELINE config 2, N > 1 config 3 (the same 1 M reads for
+    every N: strong scaling), --config forces one, and any overridden figure turns the label into "custom"."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    w1 = bench.resolve_workload(bench.parse([]), 1)
+    assert (w1["config"], w1["reads"], w1["kmers"], w1["k"]) == (2, 100_000, 50_000_000, 21) and w1["label"].startswith("config2:")
+    for n in (2, 4, 8):
+        w = bench.resolve_workload(bench.parse(["--gpus", str(n)]), n)
+        assert (w["config"], w["reads"], w["kmers"], w["k"], w["junctions"]) == (3, 1_000_000, 200_000_000, 21, False)
+        assert w["label"].startswith("config3:") and "over %d GPU" % n in w["label"]
+    w4 = bench.resolve_workload(bench.parse(["--config", "4"]), 1)
+    assert w4["junctions"] and w4["label"].startswith("config4:") and "junction" in w4["label"]
+    w5 = bench.resolve_workload(bench.parse(["--config", "5"]), 1)
+    assert (w5["k"], w5["kmers"], w5["mixed"]) == (31, 500_000_000, True) and "20 kb" in w5["label"]
+    wk = bench.resolve_workload(bench.parse(["--k", "31", "--reads", "5000"]), 1)
+    assert wk["label"].startswith("custom (config2 with reads, k changed)") and wk["k"] == 31 and wk["reads"] == 5000
+    assert "config2:" not in wk["label"]

@@ -490,10 +490,22 @@ def test_walk_tables_with_counts_beyond_their_fields(form):
 
 
 # ---------------------------------------------------------------- device table builder
-def test_device_built_table_equals_host_built_table(tmp_path):
-    """talc_table_from_arrays_device / talc_table_build_device against the host builder on the same dump: same size,
-    and the same answer for every stored k-mer (duplicates with different counts included: first wins), for k-mers
-    that are not stored, after junction colouring and homopolymer de-colouring, and through the text parser."""
+def _revcomp_packed(km, k):
+    s = unpack_kmer(km, k)
+    r = rc(s)
+    v = 0
+    for ch in r:
+        v = (v << 2) | "ACGT".index(ch)
+    return v
+
+
+def test_device_built_table_matches_the_oracle_table(tmp_path):
+    """buildCDBG on the GPU (talc_table_from_arrays_device / talc_table_build_device: insertion, junction colouring on
+    both strands, homopolymer de-colouring, all as kernels on the device-resident image) against the ORACLE's table
+    built from the same dump: same size and the same (count, colour) for every stored k-mer — duplicated lines with
+    other counts included (first wins), junction lines that reach the same k-mer several times with other colours
+    (last wins), colours at and above colouredCountThr, negative ones — for k-mers that are not stored, through the
+    host image, on the device, and through the text parser.  The host builder is held to the same answers."""
     from talc_amd.synth import Synth
     S = Synth(target_kmers=400_000, k=21, seed=41)
     keys, counts = S.dump_arrays()
@@ -502,29 +514,82 @@ def test_device_built_table_equals_host_built_table(tmp_path):
     dup = rng.integers(0, len(keys), 5000)
     keys2 = np.concatenate([keys[dup[:500]], keys, keys[dup]])
     counts2 = np.concatenate([np.ones(500, np.uint32), counts, (counts[dup] + 7).astype(np.uint32)])
-    p = T.default_params(k=21, use_junctions=1)
+    p, q = PU.both_params(k=21, use_junctions=1)
+    jk, jc = S.junction_arrays()
+    # junction lines that hit k-mers already coloured (the same line again with another count; the reverse complement
+    # of a coloured k-mer as a line of its own), counts at / above the threshold and a negative one
+    jd = rng.integers(0, len(jk), 3000)
+    jk2 = np.concatenate([jk, jk[jd], np.array([_revcomp_packed(x, 21) for x in jk[jd[:300]]], dtype=np.uint64)])
+    jc2 = np.concatenate([jc, (jc[jd] % 9000 + 11), np.full(300, 77, np.int64)]).astype(np.int64)
+    jc2[len(jk):len(jk) + 10] = 10000
+    jc2[len(jk) + 10:len(jk) + 20] = 9999
+    jc2[len(jk) + 20:len(jk) + 25] = -5
+    otab = O.OracleTable(q, O.OracleTable.FLAT)
+    otab.insert_packed(keys2, counts2)
+    otab.colour_packed(jk2, jc2)
+    otab.decolour()
     th = T.Table.from_arrays(keys2, counts2, p)
     td = T.Table.from_arrays(keys2, counts2, p, device=0)
-    assert len(th) == len(td) > 0
-    jk, jc = S.junction_arrays()
+    assert len(th) == len(td) == len(otab) > 0
     for t in (th, td):
-        t.colour(jk, jc)
+        t.colour(jk2, jc2)
         t.decolour_repeats()
-    q = np.concatenate([keys2, rng.integers(0, 1 << 42, 50000, dtype=np.uint64)])
-    hc, hj = th.lookup_host(q)
-    dc, dj = td.lookup_host(q)
-    assert (hc == dc).all() and (hj == dj).all()
-    td.upload(0)
-    gc, gj = td.lookup(q)
-    assert (gc == hc).all() and (gj == hj).all()
-    # through the text parser
+    hom = np.array([0, (1 << 42) - 1, int("01" * 21, 2), int("10" * 21, 2)], dtype=np.uint64)
+    qs = np.concatenate([keys2, rng.integers(0, 1 << 42, 50000, dtype=np.uint64), jk2,
+                         np.array([_revcomp_packed(x, 21) for x in jk2[:2000]], dtype=np.uint64), hom])
+    oc, oj = otab.lookup_packed(qs)
+    assert int((oj > 0).sum()) > 1000
+    hc, hj = th.lookup_host(qs)
+    assert (hc == oc).all() and (hj == oj).all()
+    dc, dj = td.lookup_host(qs)            # the device-resident image, copied back for this call
+    assert (dc == oc).all() and (dj == oj).all()
+    td.upload(0)                            # adopts the image where it is
+    gc, gj = td.lookup(qs)
+    assert (gc == oc).all() and (gj == oj).all()
+    for direction in (0, 1):                # the LEFT table carries the same colours
+        g4c, g4j = td.next_counts(jk2[:400], direction)
+        for i in range(0, 400, 5):
+            e4c, e4j = otab.next_counts(unpack_kmer(jk2[i], 21), direction)
+            assert e4c.tolist() == g4c[i].tolist() and e4j.tolist() == g4j[i].tolist(), (i, direction)
+    # through the text parser (buildCDBG + decolourRepeatsFromDBG as main.cpp:231-232 calls them)
     dump = str(tmp_path / "d.txt")
     S.write_dump(dump)
     junc = str(tmp_path / "j.txt")
     S.write_junctions(junc)
+    ofile = O.OracleTable(q, O.OracleTable.FLAT)
+    ost = ofile.build_from_files(dump, junc)
     fh = T.Table.from_files(dump, junc, p)
     fd = T.Table.from_files(dump, junc, p, device=0)
-    assert len(fh) == len(fd) and (fh.build_stats == fd.build_stats).all()
-    a = fh.lookup_host(q)
-    b = fd.lookup_host(q)
+    assert len(fh) == len(fd) == len(ofile) and (fh.build_stats == fd.build_stats).all()
+    assert int(fd.build_stats[0]) == int(ost[0]) and int(fd.build_stats[1]) == int(ost[1])
+    ec, ej = ofile.lookup_packed(qs)
+    a = fh.lookup_host(qs)
+    b = fd.lookup_host(qs)
+    assert (a[0] == ec).all() and (a[1] == ej).all() and (b[0] == ec).all() and (b[1] == ej).all()
+
+
+def test_table_image_export_and_import():
+    """Replication across GPUs: the device image leaves one table as two plain byte arrays in caller-owned
+    device buffers and becomes a table again on the importing side; same answers, same corrected records."""
+    import torch
+    pair = PU.Pair(target_kmers=300_000, k=21, seed=52, junctions=True)
+    pair.upload(0)
+    nb = pair.ttab.image_bytes
+    assert nb == pair.ttab.capacity * 32
+    br = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+    bl = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+    pair.ttab.export_device(0, br.data_ptr(), bl.data_ptr())
+    t2 = T.Table.import_device(pair.p, pair.ttab.capacity, len(pair.ttab), br.data_ptr(), bl.data_ptr(), 0)
+    del br, bl
+    assert len(t2) == len(pair.ttab)
+    t2.upload(0)
+    rng = np.random.default_rng(9)
+    qs = np.concatenate([pair.keys[:30000], rng.integers(0, 1 << 42, 10000, dtype=np.uint64)])
+    a, b = pair.ttab.lookup(qs), t2.lookup(qs)
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    ctx2 = T.Context(t2, pair.p, 0)
+    bases, offs = pair.reads(0, 120)
+    r1 = pair.ctx.correct(bases, offs)
+    r2 = ctx2.correct(bases, offs)
+    assert all(np.array_equal(x, y) for x, y in zip(r1, r2))
+    ctx2.close()

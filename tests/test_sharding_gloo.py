@@ -1,6 +1,8 @@
-"""The N>1 path on CPU: world_size-2 `gloo` processes shard a read set, "correct" their shard
-(a stand-in transform here: the GPU kernels are covered by the -m gpu tests) and gather the
-records on rank 0, which must see them in input order."""
+"""The N>1 path on CPU: world_size-2 `gloo` processes shard a read set exactly as bench.py does (shard_bounds over the
+read lengths), take their shard's corrected records — canned here from the CPU oracle, in the (records, offsets,
+status) form talc_batch_fetch_corrected returns; the GPU kernels themselves are covered by the -m gpu tests — pack
+them with the real payload code, gather them on rank 0 and merge: rank 0 must hold what correcting the whole read
+set in one piece gives, in input order."""
 import os
 import subprocess
 import sys
@@ -39,27 +41,34 @@ WORKER = textwrap.dedent("""
     import torch
     import torch.distributed as dist
     sys.path.insert(0, %r)
+    sys.path.insert(0, os.path.join(%r, "tests"))
     from talc_amd import sharding as SH
+    from talc_amd.synth import Synth
+    import oracle_lib as O
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(123)                      # same read set on every rank
-    lengths = rng.integers(30, 400, 57)
-    reads = [bytes(rng.choice(list(b"ACGT"), int(n)).astype(np.uint8)) for n in lengths]
+    # the same synthetic workload on every rank (every read depends on (seed, index) only)
+    S = Synth(target_kmers=60_000, k=21, seed=77)
+    keys, counts = S.dump_arrays()
+    q = O.params(k=21)
+    tab = O.OracleTable(q, O.OracleTable.FLAT)
+    tab.insert_packed(keys, counts)
+    tab.decolour()
+    N = 41
+    lengths = S.read_lengths(0, N)
     b = SH.shard_bounds(lengths, world)
-    mine = reads[b[rank]:b[rank + 1]]
-    # stand-in for the per-read correction: reverse the read, status = length %% 4
-    out = [r[::-1] for r in mine]
-    offs = np.concatenate([[0], np.cumsum([len(x) for x in out])]).astype(np.uint64)
-    st = np.array([len(x) %% 4 for x in out], dtype=np.int32)
-    payload = torch.from_numpy(SH.pack_records(b"".join(out), offs, st).copy())
+    bases, offs = S.reads(b[rank], b[rank + 1] - b[rank])
+    out, oo, st = tab.correct_batch(bases, offs, nthreads=2)      # canned fetch_corrected result of this shard
+    payload = SH.pack_records_device(torch, torch.from_numpy(out.copy()), oo, st)
+    assert bytes(payload.numpy()) == bytes(SH.pack_records(out.tobytes(), oo, st))
     got = SH.gather_records(payload, dist, rank, world, dst=0)
     if rank == 0:
         seq, o, s = SH.merge_in_order([g.numpy() for g in got])
-        exp = [r[::-1] for r in reads]
-        assert seq == b"".join(exp)
-        assert o.tolist() == np.concatenate([[0], np.cumsum([len(x) for x in exp])]).tolist()
-        assert s.tolist() == [len(x) %% 4 for x in exp]
-        print("GATHER_OK", len(exp))
+        wb, wo = S.reads(0, N)
+        e_out, e_oo, e_st = tab.correct_batch(wb, wo, nthreads=2)  # the whole set in one piece
+        assert seq == e_out.tobytes() and o.tolist() == e_oo.tolist() and s.tolist() == e_st.tolist()
+        assert (e_st == 0).sum() > N // 2
+        print("GATHER_OK", len(s))
     else:
         assert got is None
     dist.barrier()
@@ -69,7 +78,7 @@ WORKER = textwrap.dedent("""
 
 def test_two_rank_gloo_gather_restores_input_order(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
+    script.write_text(WORKER % (ROOT, ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
     procs = []
     for r in range(2):
@@ -77,4 +86,4 @@ def test_two_rank_gloo_gather_restores_input_order(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK 57" in outs[0]
+    assert "GATHER_OK 41" in outs[0]
