@@ -295,11 +295,11 @@ def committed_pmc(lib_hash, w, reads_rank):
 
 def host_to_host(T, table, params, dev, bases, offs, passes, log):
     """SURVEY §8d's phase as the reference has it — first read submitted from host memory to last corrected record back
-    in host memory (the replacement of main.cpp:247-310) — never `value`.  The workload goes through in 4 sub-batches on
-    two contexts (two host threads, one stream each, pinned staging buffers of the library), so that one sub-batch's
+    in host memory (the replacement of main.cpp:247-310) — never `value`.  The workload goes through in 2-4 sub-batches on
+    two contexts (two host threads, one stream each, pinned buffers from talc_pinned_alloc), so that one sub-batch's
     H2D / D2H copies run under the other's kernels: the streaming form the CLI uses (io.cpp:26-75 replaced)."""
     n = len(offs) - 1
-    nsub = 4 if n >= 4000 else 1
+    nsub = 4 if n >= 400_000 else (2 if n >= 4000 else 1)   # (small sub-batches leave k_search's waves a long tail)
     cuts = [n * i // nsub for i in range(nsub + 1)]
     subs, pins = [], []
     for i in range(nsub):

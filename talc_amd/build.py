@@ -137,8 +137,18 @@ def build_all(force=False):
     build_oracle()
 
 
+def build_hip_variants():
+    """Experiment builds: other occupancy targets for k_search (select one with TALC_LIB=...)."""
+    out = []
+    for w in (4, 6):
+        out.append(build_hip(False, ("-DTALC_SEARCH_WAVES_PER_SIMD=%d" % w,), "libtalc_hip_w%d.so" % w))
+    return out
+
+
 if __name__ == "__main__":
-    if "--prof" in sys.argv:
+    if "--variants" in sys.argv:
+        build_hip_variants()
+    elif "--prof" in sys.argv:
         build_hip_prof(force="--force" in sys.argv)
     else:
         build_all(force="--force" in sys.argv)

@@ -378,7 +378,7 @@ int talc_table_decolour_repeats(talc_table* t) {
 uint64_t talc_table_size(const talc_table* t) { return t ? t->h.nkmers : 0; }
 uint64_t talc_table_device_bytes(const talc_table* t) {
   if (!t) return 0;
-  uint64_t b = 2 * t->h.capacity * sizeof(Bucket) + std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64) * 8;
+  uint64_t b = 2 * t->h.capacity * sizeof(Bucket) + ((std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64) + 7) & ~7ull) * 8;
   for (const auto& kv : t->h.dev)   // walk tables, where an upload built them
     if (kv.second.walkRight) { b += 2 * t->h.capacity * sizeof(WalkEntry); break; }
   return b;
@@ -403,12 +403,12 @@ int talc_table_upload(talc_table* t, int device) {
     HIPCHK(hipMemcpy(dc.left, t->h.left, bytes, hipMemcpyHostToDevice));
   }
   {   // presence filter, from the RIGHT table
-    dc.filterWords = std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64);
+    dc.filterWords = (std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64) + 7) & ~7ull;   // whole 64-byte blocks
     HIPCHK(hipMalloc((void**)&dc.filter, dc.filterWords * 8));
     HIPCHK(hipMemset(dc.filter, 0, dc.filterWords * 8));
     if (t->h.capacity)
       hipLaunchKernelGGL(k_build_filter, dim3((unsigned)((t->h.capacity + 255) / 256)), dim3(256), 0, 0, dc.right, t->h.capacity,
-                         (unsigned long long*)dc.filter, dc.filterWords);
+                         t->h.p.k, (unsigned long long*)dc.filter, dc.filterWords);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
   }

@@ -83,8 +83,9 @@ struct TableView {
   uint64_t capacity;     // buckets per table (any size below 2^32; home = table_home(key, capacity))
   uint32_t k;
   // presence filter over the stored K-mers (blocked Bloom: three bits of one 64-bit word per k-mer, ~10 bits per
-  // k-mer): small enough to stay in the last-level cache, it answers most lookups of k-mers that are NOT in the
-  // table (93 % of a noisy read's k-mers) without touching the table.  nullptr / 0 = no filter.
+  // k-mer, 64-byte blocks chosen by the k-mer's minimizer): small enough to stay in the last-level cache, it answers
+  // most lookups of k-mers that are NOT in the table (93 % of a noisy read's k-mers) without touching the table.
+  // nullptr / 0 = no filter.  filterWords is a multiple of 8.
   const uint64_t* filter;
   uint64_t filterWords;
   const WalkEntry* walkRight;   // walk tables of `right` / `left`; nullptr = not built (the fast-forward probes per step)
@@ -107,7 +108,39 @@ TALC_HD uint64_t table_hash(uint64_t key) { const uint64_t x = key ^ (key >> 29)
 TALC_HD uint64_t table_slot(uint64_t h, uint64_t cap) { return ((h >> 32) * (uint64_t)(uint32_t)cap) >> 32; }
 TALC_HD uint64_t table_home(uint64_t key, uint64_t cap) { return table_slot(table_hash(key), cap); }
 
+// Presence filter, blocked by MINIMIZER: the filter is an array of 64-byte blocks (8 words); a k-mer's block is chosen
+// by the smallest hash among its (K - M + 1) M-mers, its word inside the block and its 3 bits by a hash of the whole
+// k-mer.  Consecutive k-mers of a read share their minimizer for (K - M + 1) / 2 positions on average, so the lanes of
+// a wave that probe consecutive positions ask for a handful of distinct 64-byte lines instead of one each — the
+// probe kernel's cost is random memory requests, not bytes.  Builder (k_build_filter) and prober (k_coverage) share
+// these functions, so the filter has no false negatives by construction; false positives only cost a bucket probe.
+#define TALC_MINIMIZER_M 11
+TALC_HD uint32_t mmer_hash(uint32_t mmer) {   // 22-bit M-mer -> 32-bit hash (0xFFFFFFFF is reserved: "contains N")
+  uint32_t x = mmer * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+  return x == 0xFFFFFFFFu ? 0xFFFFFFFEu : x;
+}
+TALC_HD uint64_t filter_block(uint32_t minHash, uint64_t nBlocks) {   // (the minimum of several hashes is not uniform: mix it again)
+  uint32_t x = minHash * 0xC2B2AE3Du; x ^= x >> 16; x *= 0x27D4EB2Fu; x ^= x >> 15;
+  return ((uint64_t)x * nBlocks) >> 32;
+}
+// reference form, from a packed k-mer (first base most significant); the prober takes the same minimum from LDS.
+// M-mers are hashed in little-endian form (base i of the M-mer at bits [2i, 2i+1]), the form they have in the
+// prober's staged window.
+TALC_HD uint32_t kmer_min_hash(uint64_t kmer, uint32_t K) {
+  uint64_t x = kmer;   // reverse the 2-bit groups: base j of the k-mer to bits [2j, 2j+1]
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  x = __builtin_bswap64(x) >> (64 - 2 * K);
+  uint32_t best = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i + TALC_MINIMIZER_M <= K; ++i) {
+    const uint32_t h = mmer_hash((uint32_t)(x >> (2 * i)) & ((1u << (2 * TALC_MINIMIZER_M)) - 1));
+    best = h < best ? h : best;
+  }
+  return best;
+}
 TALC_HD uint64_t filter_hash(uint64_t kmer) { return mix64(kmer ^ 0x9E3779B97F4A7C15ULL); }
+TALC_HD uint32_t filter_word(uint64_t h) { return (uint32_t)(h >> 61); }   // word of the block
 TALC_HD uint64_t filter_mask(uint64_t h) { return (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63)) | (1ULL << ((h >> 12) & 63)); }
 
 // ------------------------------------------------------------------ Dna5 codes

@@ -184,18 +184,20 @@ __global__ void k_decolour_repeats(Bucket* __restrict__ right, Bucket* __restric
   if (sl != ~0ULL && left[sl].cnt[b] != 0) left[sl].jc[b] = 0;
 }
 
-// presence filter (TableView::filter) from the RIGHT table, one thread per bucket
-__global__ void k_build_filter(const Bucket* __restrict__ right, uint64_t cap, unsigned long long* __restrict__ filter,
+// presence filter (TableView::filter; talc_common.h: blocks by minimizer) from the RIGHT table, one thread per bucket
+__global__ void k_build_filter(const Bucket* __restrict__ right, uint64_t cap, uint32_t K, unsigned long long* __restrict__ filter,
                                uint64_t nWords) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cap) return;
   const BucketRegs r = load_bucket(right + j);
   if (r.key == kEmptyKey) return;
+  const uint64_t nBlocks = nWords >> 3;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     if (r.cnt[b] == 0) continue;
-    const uint64_t h = filter_hash((r.key << 2) | (uint64_t)b);
-    atomicOr(&filter[__umul64hi(h, nWords)], (unsigned long long)filter_mask(h));
+    const uint64_t km = (r.key << 2) | (uint64_t)b;
+    const uint64_t h = filter_hash(km);
+    atomicOr(&filter[filter_block(kmer_min_hash(km, K), nBlocks) * 8 + filter_word(h)], (unsigned long long)filter_mask(h));
   }
 }
 

@@ -92,13 +92,27 @@ __global__ void k_encode(const uint8_t* __restrict__ raw, uint8_t* __restrict__ 
 // ------------------------------------------------------------------ coverage (the k-mer probe kernel)
 // One block per tile of up to COV_TILE consecutive k-mer positions of ONE read.
 //  1. the tile's base window (COV_TILE + K - 1 codes) is staged into LDS as 2-bit packed words
-//     plus an N bitmap (coalesced byte loads, 8 bases per thread per pass);
-//  2. thread t takes positions t, t+256, ... : the k-mer is two LDS words funnel-shifted;
-//     its (K-1)-prefix is hashed and the 32-byte bucket probed in HBM (the only random access);
-//  3. (count, colour) is written as one 8-byte store per k-mer, coalesced across the wave;
-//  4. #{count > MIN_COUNT} (Read.cpp:190) is reduced per block and added to the read's counter.
+//     plus an N bitmap (coalesced byte loads, 16 bases per thread per pass);
+//  2. the hash of every M-mer of the window goes to LDS (one per thread per pass): a k-mer's minimizer hash is the
+//     minimum of K - M + 1 consecutive entries, and it selects the k-mer's 64-byte block of the presence filter —
+//     thread t takes positions t, t+256, ..., so the lanes of a wave probe consecutive positions, which share their
+//     minimizer in runs: a wave's filter probes touch a handful of distinct 64-byte lines instead of 64;
+//  3. the k-mer itself is two LDS words funnel-shifted; only if the filter says "maybe" (7-9 % of a noisy read's
+//     positions) is the 32-byte bucket of its (K-1)-prefix probed in HBM, and for a k-mer that is in the table the
+//     two buckets that give its out-degrees;
+//  4. (count, colour | degrees) is written as one 8-byte store per k-mer, coalesced across the wave;
+//  5. #{count > MIN_COUNT} (Read.cpp:190) is reduced per block and added to the read's counter.
 #define COV_TILE 2048
 #define COV_THREADS 256
+
+// the 2-bit groups of x reversed (group g <-> group 31 - g)
+TALC_HD uint64_t rev2bit64(uint64_t x) {
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+#if defined(__HIPCC__) || defined(__GNUC__)
+  return __builtin_bswap64(x);
+#endif
+}
 
 __global__ void __launch_bounds__(COV_THREADS)
 k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
@@ -107,8 +121,10 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
            uint32_t min_count) {
   __shared__ uint64_t s_pack[(COV_TILE + 64) / 32 + 2];
   __shared__ uint64_t s_nmask[(COV_TILE + 64) / 64 + 2];
+  __shared__ uint32_t s_mh[COV_TILE + 64];          // hash of the M-mer starting at each window position
   __shared__ int s_nin;
   const uint32_t K = T.k;
+  constexpr uint32_t M = TALC_MINIMIZER_M;
   const uint32_t r = tile_read[blockIdx.x];
   const uint32_t p0 = tile_start[blockIdx.x];
   const uint64_t rb = offsets[r];
@@ -116,7 +132,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   const uint32_t nk = L - K + 1;                       // k-mers in this read (host guarantees L >= K)
   const uint32_t cnt = min((uint32_t)COV_TILE, nk - p0);  // positions in this tile
   const uint32_t wlen = cnt + K - 1;                  // bases in the window
-  const uint8_t* src = codes + rb + p0;
+  const uint8_t TALC_AS1* src = (const uint8_t TALC_AS1*)(codes + rb + p0);
 
   if (threadIdx.x == 0) s_nin = 0;
   // stage: 16 bases -> one u32 of 2-bit codes + 16 N bits, per thread per pass
@@ -136,39 +152,52 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
       pk32[g] = w;
       nm16[g] = (uint16_t)nm;
     }
-    // zero one guard word so the funnel shift below never reads uninitialised LDS
-    if (threadIdx.x == 0) { pk32[ngroups] = 0; pk32[ngroups + 1] = 0; nm16[ngroups] = 0; nm16[ngroups + 1] = 0;
-                            nm16[ngroups + 2] = 0; nm16[ngroups + 3] = 0; }
+    // zero the guard words so that the funnel shifts below never read uninitialised LDS
+    if (threadIdx.x == 0) { pk32[ngroups] = 0; pk32[ngroups + 1] = 0; pk32[ngroups + 2] = 0; pk32[ngroups + 3] = 0;
+                            nm16[ngroups] = 0; nm16[ngroups + 1] = 0; nm16[ngroups + 2] = 0; nm16[ngroups + 3] = 0; }
+  }
+  __syncthreads();
+
+  // little-endian window bits [2q, 2q + 64) and N bits [q, q + 64)
+  auto window = [&](uint32_t q, uint64_t& le, uint64_t& nb) {
+    const uint32_t bit = 2 * q, w = bit >> 6, sh = bit & 63;
+    const uint64_t lo = s_pack[w], hi = s_pack[w + 1];
+    le = (sh == 0) ? lo : ((lo >> sh) | (hi << (64 - sh)));
+    const uint32_t nw = q >> 6, nsh = q & 63;
+    const uint64_t nlo = s_nmask[nw], nhi = s_nmask[nw + 1];
+    nb = (nsh == 0) ? nlo : ((nlo >> nsh) | (nhi << (64 - nsh)));
+  };
+  // M-mer hashes of the window (an M-mer with an N never is the minimum: such k-mers are not looked up at all)
+  const uint32_t nmm = wlen - M + 1;                 // K >= 18 > M
+  for (uint32_t q = threadIdx.x; q < nmm; q += COV_THREADS) {
+    uint64_t le, nb;
+    window(q, le, nb);
+    const uint32_t mm = (uint32_t)le & ((1u << (2 * M)) - 1);   // base q+i at bits [2i, 2i+1]
+    s_mh[q] = (nb & ((1ull << M) - 1)) ? 0xFFFFFFFFu : mmer_hash(mm);
   }
   __syncthreads();
 
   const uint64_t kbits = 2ull * K;
   const uint64_t kmaskLE = (K >= 32) ? ~0ULL : ((1ULL << kbits) - 1);
+  const uint64_t nBlocks = T.filterWords >> 3;
+  const uint64_t TALC_AS1* filter = (const uint64_t TALC_AS1*)T.filter;
+  const uint32_t nwin = K - M + 1;                   // M-mers per k-mer
   int local_in = 0;
   uint2* out = cov + koff[r] + p0;
   for (uint32_t p = threadIdx.x; p < cnt; p += COV_THREADS) {
-    // little-endian packed window: base i at bits [2i,2i+1] of the bit stream
-    const uint32_t bit = 2 * p;
-    const uint32_t w = bit >> 6, sh = bit & 63;
-    uint64_t lo = s_pack[w], hi = s_pack[w + 1];
-    uint64_t le = (sh == 0) ? lo : ((lo >> sh) | (hi << (64 - sh)));
+    uint64_t le, nb;
+    window(p, le, nb);
     le &= kmaskLE;  // base p+i at bits [2i, 2i+1]
-    // N test: any N among bases [p, p+K)
-    const uint32_t nw = p >> 6, nsh = p & 63;
-    uint64_t nlo = s_nmask[nw], nhi = s_nmask[nw + 1];
-    uint64_t nb = (nsh == 0) ? nlo : ((nlo >> nsh) | (nhi << (64 - nsh)));
-    nb &= (K >= 64) ? ~0ULL : ((1ULL << K) - 1);
-    // convert to the table's big-endian packing (first base most significant): reverse 2-bit groups
-    uint64_t x = le;
-    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-    x = __builtin_bswap64(x);
-    const uint64_t kmer = x >> (64 - kbits);
+    nb &= (K >= 64) ? ~0ULL : ((1ULL << K) - 1);   // any N among bases [p, p+K)
+    // the table's big-endian packing (first base most significant): reverse the 2-bit groups
+    const uint64_t kmer = rev2bit64(le) >> (64 - kbits);
     uint32_t c = 0, j = 0;
     bool maybe = (nb == 0);
-    if (maybe && T.filter) {   // presence filter first: one 8-byte word from a cache-resident array
+    if (maybe && filter) {   // presence filter first: one 8-byte word of the minimizer's 64-byte block
+      uint32_t mh = s_mh[p];
+      for (uint32_t i = 1; i < nwin; ++i) mh = min(mh, s_mh[p + i]);
       const uint64_t h = filter_hash(kmer), m = filter_mask(h);
-      maybe = (T.filter[__umul64hi(h, T.filterWords)] & m) == m;
+      maybe = (filter[filter_block(mh, nBlocks) * 8 + filter_word(h)] & m) == m;
     }
     if (maybe) dev_get_count(T, kmer, c, j);
     if (c != 0) {

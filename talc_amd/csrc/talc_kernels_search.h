@@ -50,7 +50,8 @@ struct FullMeta { uint32_t off, len; int32_t lanc, ranc; double dist; };
 
 // per-wave scratch layout (byte offsets inside one slot)
 struct SearchCaps {
-  uint32_t seqCap;      // bytes per Trail sequence
+  uint32_t seqCap;      // bytes per Trail sequence (host: the longest possible; device: the current search's stride)
+  uint32_t seqArena;    // bytes of the arena the Trail buffers are cut from
   uint32_t refCap;      // bytes of currentRefSeq
   uint32_t edgeCap;     // bytes per edge candidate sequence
   uint32_t anchCap;     // anchors per side
@@ -80,25 +81,33 @@ struct TrailSetLayout {
   static constexpr uint64_t bytes = buf + 4ull * TCAP;
 };
 
-// Scratch of one wave.  A Trail is at most K + PATH_MAXLENGTH = 1.2 gap + 4 K bases long (Explorer.cpp:919,1036), and
-// the pool holds NBUF such buffers, so the pool is what the slot size hangs on.  The first pass sizes the buffers for
-// gaps up to `seqLimit` bases (nearly every gap of a noisy read is a few hundred bases, whatever the read's length:
-// 20 kb reads would otherwise cost 14 MB per wave); a search that outgrows its buffer raises OVF_SEQ and the read goes
-// to the retry passes, which size everything from the batch's longest read (seqLimit = 0: a path can then never
-// outgrow its buffer) and multiply the counted capacities (anchors, recorded bridges) by `scale`.
-static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, uint32_t seqLimit, bool tiny = false) {
+// Scratch of one wave.  A Trail of a search is at most K + PATH_MAXLENGTH = 1.2 gap + 4 K bases long
+// (Explorer.cpp:919,1036), known when the search starts: the Trail buffers of a search are cut from one arena with
+// that stride (X.C.seqCap is set per search), so a short gap gets the full NBUF buffers and a 20 kb gap still a few
+// dozen — nearly every gap of a noisy read is a few hundred bases whatever the read's length, and sizing all NBUF
+// buffers for the longest read would cost 14 MB per wave at 20 kb.  A search that needs more buffers than its stride
+// leaves (many live Trails in a very long gap) raises OVF_TRAILS / OVF_SEQ and the read goes to the retry passes,
+// whose arena holds NBUF buffers of the longest possible Trail and whose counted capacities (anchors, recorded
+// bridges) are multiplied by `scale`.  arenaLimit (first pass only; 0 = the default) is a test hook.
+static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, uint32_t arenaLimit, bool tiny = false) {
   SearchCaps c;
   memset(&c, 0, sizeof c);
   const uint64_t Lm = maxLen;
-  const uint64_t gapMax = (seqLimit && seqLimit < Lm) ? seqLimit : Lm;
-  c.seqCap = (uint32_t)align_up((uint64_t)(1.2 * (double)gapMax) + 4ull * K + 64, 16);
+  c.seqCap = (uint32_t)align_up((uint64_t)(1.2 * (double)Lm) + 4ull * K + 64, 16);   // the longest Trail of any search
+  const uint64_t fullArena = (uint64_t)NBUF * c.seqCap;
+  uint64_t arena = fullArena;
+  if (scale == 1) {
+    arena = std::min<uint64_t>(fullArena, std::max<uint64_t>(1ull << 20, 8ull * c.seqCap));
+    if (arenaLimit) arena = std::min<uint64_t>(arena, arenaLimit);
+  }
+  c.seqArena = (uint32_t)align_up(std::min<uint64_t>(arena, 0xFFFFFF00ull), 16);
   c.refCap = (uint32_t)align_up(Lm + 2ull * K + 64, 16);
   c.edgeCap = (uint32_t)align_up((uint64_t)c.seqCap + c.refCap, 16);
   // (a region of n k-mers records at most n positions: beyond that the anchor lists cannot overflow)
   c.anchCap = (uint32_t)std::min<uint64_t>(256ull * scale, Lm + 8);
   if (c.anchCap < 8) c.anchCap = 8;
   c.fullCap = 128 * scale;
-  c.fullPool = (uint32_t)align_up((uint64_t)c.seqCap * 16 * scale, 16);
+  c.fullPool = (uint32_t)align_up(std::max<uint64_t>(65536, 4ull * c.seqCap) * scale, 16);
   c.dpCap = (uint32_t)align_up(std::max<uint64_t>(c.edgeCap, c.seqCap) + 8, 4);
   if (c.dpCap < 1024) c.dpCap = 1024;   // (the phased x-drop keeps its hand-over state in these arrays)
   if (tiny) { c.anchCap = 3; c.fullCap = 1; c.fullPool = (uint32_t)align_up((uint64_t)c.seqCap, 16); }  // test hook: force the retry pass
@@ -108,7 +117,7 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   auto take = [&](uint64_t bytes) { uint64_t r = o; o = align_up(o + bytes, 16); return r; };
   c.o_setA = take(TrailSetLayout::bytes);
   c.o_setB = take(TrailSetLayout::bytes);
-  c.o_seqPool = take((uint64_t)NBUF * c.seqCap);
+  c.o_seqPool = take(c.seqArena);
   c.o_ref = take(c.refCap);
   c.o_ancL = take((uint64_t)c.anchCap * sizeof(AnchorRec));
   c.o_ancR = take((uint64_t)c.anchCap * sizeof(AnchorRec));
@@ -148,19 +157,23 @@ TALC_D void wave_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, u
   kmer = v;
 }
 
-// the same for one position per lane (K byte loads each)
-TALC_D void lane_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, uint64_t& nmask) {
+// the same for one position per lane (K byte loads each).  A rare path (k_coverage leaves the degrees of every table
+// k-mer next to its count), so it is a real function: its registers do not weigh on its callers.
+TALC_DN void lane_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, uint64_t& nmask) {
   gcu8 g = (gcu8)s;
-  // all the byte loads are issued before the first one is used (K <= 31; the index is clamped, never out of the read)
-  uint32_t c[31];
-#pragma unroll
-  for (int j = 0; j < 31; ++j) c[j] = (uint32_t)g[j < K ? j : K - 1];
   uint64_t v = 0, nm = 0;
+  // eight byte loads in flight at a time (K <= 31; the index is clamped, never out of the read)
 #pragma unroll
-  for (int j = 0; j < 31; ++j) {
-    if (j < K) {
-      v = (v << 2) | (uint64_t)((c[j] > 3u) ? 0u : c[j]);
-      nm |= (uint64_t)(c[j] > 3u) << j;
+  for (int j0 = 0; j0 < 32; j0 += 8) {
+    uint32_t c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = (uint32_t)g[(j0 + j) < K ? (j0 + j) : K - 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j0 + j < K) {
+        v = (v << 2) | (uint64_t)((c[j] > 3u) ? 0u : c[j]);
+        nm |= (uint64_t)(c[j] > 3u) << (j0 + j);
+      }
     }
   }
   kmer = v; nmask = nm;
@@ -468,7 +481,8 @@ struct Wv {
   // scratch
   TrailSet G[2];                    // HBM backing store of the two Trail sets (slots >= HOT)
   int ia;                           // which set is the current one ("competingPaths"); ia^1 = newCompetingPaths
-  uint8_t* seqPool;                 // NBUF buffers of seqCap bytes
+  uint8_t* seqPool;                 // the arena: nBuf buffers of C.seqCap bytes (per search)
+  uint32_t nBuf;
   unsigned long long freeMask[NBUF / 64];   // wave-uniform free bitmap of the pool
   uint8_t *ref, *fullPool, *edgeLong, *edgeShort, *edgeTmp, *weak;
   AnchorRec *ancL, *ancR; uint32_t* ancPos;
@@ -637,9 +651,19 @@ TALC_D void trace_rec(int kind, int a, int b, int c, int d, double x, const uint
 // Trails are flat byte strings; a child that is the LAST successor of its parent takes over the
 // parent's buffer and just appends its base (the common single-path case copies nothing), the
 // other children get a fresh buffer and copy.  The free bitmap is wave-uniform register state.
-TALC_D void pool_reset() {
+TALC_D void pool_reset() {   // buffers 0 .. nBuf-1 are free
+  const int nb = (int)X.nBuf;
 #pragma unroll
-  for (int w = 0; w < NBUF / 64; ++w) X.freeMask[w] = ~0ull;
+  for (int w = 0; w < NBUF / 64; ++w) X.freeMask[w] = (nb >= 64 * (w + 1)) ? ~0ull : (nb > 64 * w ? ((1ull << (nb - 64 * w)) - 1) : 0ull);
+}
+// the Trail buffers of the search that starts now: stride for paths of up to K + pathMax bases (+ the base a step
+// appends before it checks its limits), as many of them as the arena holds
+TALC_D bool pool_shape(uint32_t pathMax) {
+  const uint32_t stride = (X.P.K + pathMax + 16u + 15u) & ~15u;
+  if (stride > X.C.seqArena) { X.overflow |= OVF_SEQ; return false; }
+  X.C.seqCap = stride;
+  X.nBuf = min((uint32_t)NBUF, X.C.seqArena / stride);
+  return true;
 }
 TALC_D int pool_alloc() {
   int id = -1;
@@ -936,8 +960,8 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
 // getSeedAndExtension without the score (the form findStopPosition uses) from a given extension (extCols on the
 // query = the shorter sequence, extRows on the other)
 TALC_D SeedExt seedext_plain(int refLen, int candLen, int extCols, int extRows, int xdrop) {
-  const int K = (int)X.P.K;
-  const int S = X.dirRight ? K - 1 : K;
+  const int K = uni((int)X.P.K);
+  const int S = uni(X.dirRight) ? K - 1 : K;
   const bool state = !(refLen < candLen);
   const int qlen = (state ? candLen : refLen) - S, dlen = (state ? refLen : candLen) - S;
   if (!(qlen > 0 && dlen > 0)) { extCols = 0; extRows = 0; }
@@ -981,54 +1005,72 @@ TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint
 }
 
 // Trail::seedAndExtend (Trail.cpp:193-216) on slot t of set S; returns `ok`
-TALC_DN bool trail_seed_and_extend(int set, int t, int len, int xdrop) {
+// (Everything here is wave-uniform: the arguments and the extension's results are moved to scalar registers and the
+// Trail's record is read again after the extension instead of being held across it, so that this function keeps no
+// vector register alive over the call — a vector register held over a call has to be a callee-saved one, and every
+// callee-saved register a function touches costs a scratch store and a load per call of it.)
+TALC_DN bool trail_seed_and_extend(int set_, int t_, int len_, int xdrop_) {
+  const int set = uni(set_), t = uni(t_), len = uni(len_), xdrop = uni(xdrop_);
   WSYNC();   // the Trail's last bases were appended by lane 0: make them visible to the DP lanes
+  const uint32_t buf = (uint32_t)uni((int)tr_buf(set, t));
+  const SeedExt e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)buf * X.C.seqCap, len, xdrop, true);
+  const int lenHistExt = uni(e.lenHistExt), score = uni(e.score), posOnRef = uni(e.posOnRef);
+  const bool stop = uni((int)e.stop) != 0;
   TrailRec r = tr_get(set, t);
-  const SeedExt e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)r.buf * X.C.seqCap, len, xdrop, true);
-  const bool ok1 = (e.lenHistExt == len);
+  const bool ok1 = (lenHistExt == len);
   r.fail = ok1 ? 0u : r.fail + 1u;
-  r.score = e.score;
-  if (X.dirRight) r.ranc = e.posOnRef; else r.lanc = e.posOnRef;
+  r.score = score;
+  if (X.dirRight) r.ranc = posOnRef; else r.lanc = posOnRef;
+  const bool ok = (uni((int)r.fail) <= (uint32_t)X.P.MAX_BORDER_FAILURES) & !stop;
   if (lane_id() == 0) tr_put(set, t, r);
   tr_sync(t);
-  bool ok = (r.fail <= (uint32_t)X.P.MAX_BORDER_FAILURES);
-  ok &= !e.stop;
   return ok;
 }
 
 // ------------------------------------------------------------------ recordEdge (Explorer.cpp:1103-1118)
 // Trajectory(trail) + trim + reshape + cutAnchors, then the fold of findBestBORDER
 // (Trajectory.cpp:306-334) into the best long / best short candidate.
-TALC_DN void record_edge(int set, int t, int len0) {
+TALC_DN void record_edge(int set_, int t_, int len0_) {
   PROF_DECL;
+  // (wave-uniform throughout: every value that outlives a call sits in a scalar register)
+  const int set = uni(set_), t = uni(t_), len0 = uni(len0_);
   const int K = (int)X.P.K;
   WSYNC();
-  const TrailRec tr = tr_get(set, t);
-  const uint8_t* path = X.seqPool + (uint64_t)tr.buf * X.C.seqCap;
-  const int lastScore = tr.score;
-  const double dist = tr.dist / ((double)len0 + 0.01);       // Trajectory.cpp:45
-  const uint32_t lanc = (uint32_t)tr.lanc, ranc = (uint32_t)tr.ranc;
+  uint32_t trBuf, trFail, lanc, ranc; int lastScore; unsigned long long distBits;
+  {
+    const TrailRec tr = tr_get(set, t);
+    trBuf = (uint32_t)uni((int)tr.buf); trFail = (uint32_t)uni((int)tr.fail); lastScore = uni(tr.score);
+    lanc = (uint32_t)uni(tr.lanc); ranc = (uint32_t)uni(tr.ranc);
+    distBits = uni64((unsigned long long)__double_as_longlong(tr.dist / ((double)len0 + 0.01)));   // Trajectory.cpp:45
+  }
+  const uint8_t* path = X.seqPool + (uint64_t)trBuf * X.C.seqCap;
   // trim (Trajectory.cpp:89-112)
   int len = len0;
-  const uint32_t nbBases = tr.fail * X.P.CHECK_INTERVAL;
+  const uint32_t nbBases = trFail * X.P.CHECK_INTERVAL;
   if ((uint32_t)len >= nbBases + (uint32_t)K) len = len - (int)nbBases;
-  const bool shorter = ((uint32_t)len <= X.refLen);
+  const int refLen = uni((int)X.refLen);
+  const bool shorter = (len <= refLen);
   // reshape (Trajectory.cpp:114-155) with findStopPosition (:482-503)
   int xdrop1 = (int)lastScore * (-1);
   SeedExt cur, nxt;
   // findStopPosition(A, B): `reference` = A, `shorterPath` = B
-  const uint8_t* A = shorter ? X.ref : path; const int lenA = shorter ? (int)X.refLen : len;
-  const uint8_t* Bq = shorter ? path : X.ref; const int lenB = shorter ? len : (int)X.refLen;
+  const uint8_t* A = uni_ptr(shorter ? X.ref : path); const int lenA = shorter ? refLen : len;
+  const uint8_t* Bq = uni_ptr(shorter ? path : X.ref); const int lenB = shorter ? len : refLen;
   // the loop below asks for x, x-1, x-2, ... : all of them come out of one wavefront run when the band fits
-  int* const resCols = X.dpG;
-  int* const resRows = X.dpG + X.C.dpCap;
-  int* const resScore = X.dpG + 2ull * X.C.dpCap;   // ([0, 128): below the phased x-drop's hand-over area)
+  int* const resCols = uni_ptr(X.dpG);
+  int* const resRows = resCols + X.C.dpCap;
+  int* const resScore = resCols + 2ull * X.C.dpCap;   // ([0, 128): below the phased x-drop's hand-over area)
   bool multi = false;
   if (xdrop1 >= 1 && (uint32_t)(xdrop1 + 1) <= X.C.dpCap && xdrop1 < 128)
     multi = seed_and_extension_multi(A, lenA, Bq, lenB, xdrop1, resCols, resRows, resScore);
+  auto scalar = [](SeedExt e) -> SeedExt {
+    e.lenRefExt = uni(e.lenRefExt); e.lenHistExt = uni(e.lenHistExt); e.posOnRef = uni(e.posOnRef); e.score = uni(e.score);
+    e.stop = uni((int)e.stop) != 0; e.extRef = uni(e.extRef); e.extCand = uni(e.extCand);
+    return e;
+  };
   auto ext_at = [&](int x) -> SeedExt {
     if (multi && x >= 0) return seedext_plain(lenA, lenB, uni(resCols[x]), uni(resRows[x]), x);
-    return seed_and_extension(A, lenA, Bq, lenB, x, false);
+    return scalar(seed_and_extension(A, lenA, Bq, lenB, x, false));
   };
   nxt = ext_at(xdrop1);
   bool goFurther = true;
@@ -1050,19 +1092,21 @@ TALC_DN void record_edge(int set, int t, int len0) {
   }
   // score of the retained extension (Trail.cpp:408-434)
   PROF_BEGIN();
-  double score;
-  double idscore;
+  int scoreI;        // (the score is an integer in every branch: kept as one, compared as a double below)
+  int lcs;
   {
     // score of the retained extension (Trail.cpp:408-434) and computePercentID (Trajectory.cpp:505-528):
     // -edit distance and LCS / max length of the same two extensions
-    int es, lcs;
+    int es;
     edit_and_lcs(A, cur.lenRefExt, Bq, cur.lenHistExt, es, lcs, !cur.stop && !haveScore, 0);
-    score = cur.stop ? (double)cur.score : (haveScore ? (double)multiScore : (double)es);
-    const double lenMax = (double)max(cur.lenRefExt, cur.lenHistExt);
-    idscore = (double)lcs / lenMax;
+    es = uni(es); lcs = uni(lcs);
+    scoreI = cur.stop ? cur.score : (haveScore ? multiScore : es);
   }
+  const double score = (double)scoreI;
+  const double idscore = (double)lcs / (double)max(cur.lenRefExt, cur.lenHistExt);
+  const double dist = __longlong_as_double((long long)distBits);
   // new sequence in growth order
-  uint8_t* tmp = X.edgeTmp;
+  uint8_t* tmp = uni_ptr(X.edgeTmp);
   uint32_t newLen;
   if (!shorter) {
     // prefix(path, pos) walking RIGHT / suffix(path, pos) walking LEFT == growth-order prefix of length S+ext(path)
@@ -1072,7 +1116,7 @@ TALC_DN void record_edge(int set, int t, int len0) {
   } else {
     // path followed by the rest of the reference beyond the stop position
     const uint32_t from = (uint32_t)cur.lenRefExt;
-    const uint32_t rest = X.refLen > from ? X.refLen - from : 0;
+    const uint32_t rest = (uint32_t)refLen > from ? (uint32_t)refLen - from : 0;
     newLen = (uint32_t)len + rest;
     if (newLen > X.C.edgeCap) { X.overflow |= OVF_SEQ; return; }
     wave_copy_bytes(tmp, path, (uint32_t)len, false);
@@ -1091,7 +1135,7 @@ TALC_DN void record_edge(int set, int t, int len0) {
   if (!best.have) take = true;
   else if (score > best.score) take = true;
   else if (score == best.score && dist > best.dist) take = true;
-  if (take) {
+  if (uni((int)take)) {
     best.have = true; best.score = score; best.dist = dist; best.idscore = idscore; best.len = cutLen;
     best.lanc = lanc; best.ranc = ranc;
     X.best2[bi] = best;
@@ -1296,7 +1340,7 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
           ++nNew;
         } else {
           PROF_BEGIN();
-          const bool cyc = is_cycle(t, nNew, len, km2, nm2);
+          const bool cyc = uni((int)is_cycle(t, nNew, len, km2, nm2)) != 0;
           PROF_END(PF_CYCLE);
           if (cyc) { pool_free(tr_buf(ib, nNew)); continue; }   // :586-587 pop_back
           ++nNew;
@@ -1322,7 +1366,7 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
     PROF_END(PF_SCOREBR);
     bool cx = false;
     PROF_BEGIN();
-    nOut = garden(nNew, len + 1, cx);
+    nOut = uni(garden(nNew, len + 1, cx));
     PROF_END(PF_GARDEN);
     X.complexRegion |= cx;
   } else {
@@ -1335,34 +1379,35 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
 // Explorer::scoreEdges (Explorer.cpp:709-740) on the new set (n trails of length len); survivors
 // are compacted in place; returns their number
 // (ib = the Trail set to score: the new set of a generic step, or the current set when the fast-forward took the step)
-TALC_DN int score_edges(int ib_, int n, int len, int& xdrop) {
+TALC_DN int score_edges(int ib_, int n_, int len_, int& xdrop_) {
+  const int n = uni(n_), len = uni(len_);
   if (n == 0) return 0;
   const int l = lane_id();
   const int ib = uni(ib_);
-  xdrop += 2;
+  const int xdrop = uni(xdrop_) + 2;
   int new_xdrop = 0;
   int nSel = 0;
   // trash paths are only needed when nobody survives: remember them by flag in gKept
   for (int t = 0; t < n; ++t) {
-    const bool ok = trail_seed_and_extend(ib, t, len, xdrop);
+    const bool ok = uni((int)trail_seed_and_extend(ib, t, len, xdrop)) != 0;
     if (l == 0) X.gKept[t] = ok ? 1u : 0u;
     if (ok) {
-      const int current_xdrop = (int)((double)tr_get(ib, t).score * (-1));
+      const int current_xdrop = (int)((double)uni(tr_get(ib, t).score) * (-1));
       if ((new_xdrop > current_xdrop) || (new_xdrop == 0)) new_xdrop = current_xdrop;
       ++nSel;
     }
   }
   WSYNC();
-  xdrop = new_xdrop;
+  xdrop_ = new_xdrop;
   if (nSel == 0) {
-    for (int t = 0; t < n; ++t) { record_edge(ib, t, len); pool_free(tr_buf(ib, t)); }
+    for (int t = 0; t < n; ++t) { record_edge(ib, t, len); pool_free((uint32_t)uni((int)tr_buf(ib, t))); }
     return 0;
   }
   // compact survivors to the front, keeping their order (metadata only: the sequence buffers stay
   // where they are); the buffers of the trashed Trails go back to the pool
   int w = 0;
   for (int t = 0; t < n; ++t) {
-    if (X.gKept[t]) {
+    if (uni((int)X.gKept[t])) {
       if (w != t) {
         const TrailRec r = tr_get(ib, t);
         WSYNC();
@@ -1371,7 +1416,7 @@ TALC_DN int score_edges(int ib_, int n, int len, int& xdrop) {
       }
       ++w;
     } else {
-      pool_free(tr_buf(ib, t));
+      pool_free((uint32_t)uni((int)tr_buf(ib, t)));
     }
   }
   WSYNC();
@@ -1416,7 +1461,7 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
         make_child(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
         PROF_END(PF_CHILD);
         PROF_BEGIN();
-        const bool cycle = is_cycle(t, nNew, len, km2, nm2);
+        const bool cycle = uni((int)is_cycle(t, nNew, len, km2, nm2)) != 0;
         PROF_END(PF_CYCLE);
         if (cycle || (stepCounter + 1 > PATH_MAXLENGTH)) {
           trail_seed_and_extend(ib, nNew, len + 1, xdrop);
@@ -1436,11 +1481,11 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
   ++stepCounter;
   int nOut;
   if ((stepCounter % P.CHECK_INTERVAL == 0) || ((uint32_t)nNew >= P.MAX_BORDER_PATHS)) {
-    nNew = score_edges(X.ia ^ 1, nNew, len + 1, xdrop);
+    nNew = uni(score_edges(X.ia ^ 1, nNew, len + 1, xdrop));
     if (nNew > 5) {
       bool cx = false;
       PROF_BEGIN();
-      nOut = garden(nNew, len + 1, cx);
+      nOut = uni(garden(nNew, len + 1, cx));
       PROF_END(PF_GARDEN);
       X.complexRegion |= cx;
     } else { swap_sets(); nOut = nNew; }
@@ -1831,15 +1876,23 @@ TALC_D void ref_append(uint32_t from, uint32_t to) {
 
 struct GapResult { bool found; uint32_t Le, Rs; uint32_t wOff, wLen; };
 
+// an anchor record in scalar registers (it is the same for every lane, and it lives across the whole search)
+TALC_D AnchorRec uni_anchor(const AnchorRec* p) {
+  const AnchorRec a = *p;
+  AnchorRec r;
+  r.kmer = uni64(a.kmer); r.nmask = uni64(a.nmask); r.pos = (uint32_t)uni((int)a.pos); r.count = (uint32_t)uni((int)a.count);
+  return r;
+}
+
 // Explorer::searchBridge (Explorer.cpp:868-989) after initializeINNER(…, direction)
 TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
   PROF_DECL; PROF_DECL2;
   const DevParams& P = X.P;
-  const uint32_t K = P.K;
+  const uint32_t K = (uint32_t)uni((int)P.K);
   const int l = lane_id();
-  const AnchorRec* anchors = X.dirRight ? X.ancL : X.ancR;
-  const int nAnch = X.dirRight ? X.nAncL : X.nAncR;
-  const int limit = min(nAnch, (int)P.MAX_START_ANCHORS);
+  const AnchorRec* anchors = uni_ptr(X.dirRight ? X.ancL : X.ancR);
+  const int nAnch = uni(X.dirRight ? X.nAncL : X.nAncR);
+  const int limit = min(nAnch, uni((int)P.MAX_START_ANCHORS));
   bool found = false;
   {  // the target anchors ("aims") go to LDS for the per-child aim check
     const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
@@ -1848,8 +1901,9 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
     LSYNC();
   }
   for (int s = 0; s < limit && !found; ++s) {
-    const AnchorRec a = anchors[s];
+    const AnchorRec a = uni_anchor(anchors + s);
     const uint32_t whichStart = a.pos;
+    const uint32_t Rs = (uint32_t)uni((int)X.Rs), Re = (uint32_t)uni((int)X.Re), Ls = (uint32_t)uni((int)X.Ls), Le = (uint32_t)uni((int)X.Le);
     X.nFull = 0; X.fullUsed = 0;
     uint32_t stepCounter = 0;
     // gap between the start anchor and the target region (:916-918)
@@ -1857,28 +1911,30 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
     X.refLen = 0;
     if (X.dirRight) {
       ref_append(whichStart, whichStart + K);
-      if (whichStart + K < X.Rs) { gapLen = X.Rs - (whichStart + K); ref_append(whichStart + K, X.Rs); }
-      ref_append(X.Rs, X.Re + K);
+      if (whichStart + K < Rs) { gapLen = Rs - (whichStart + K); ref_append(whichStart + K, Rs); }
+      ref_append(Rs, Re + K);
     } else {
       ref_append(whichStart, whichStart + K);
-      if (X.Le + K < whichStart) { gapLen = whichStart - (X.Le + K); ref_append(X.Le + K, whichStart); }
-      ref_append(X.Ls, X.Le + K);
+      if (Le + K < whichStart) { gapLen = whichStart - (Le + K); ref_append(Le + K, whichStart); }
+      ref_append(Ls, Le + K);
       // growth order walking LEFT = reversed text: anchor, then gap, then target, each reversed,
       // which is exactly the reverse of target+gap+anchor (:934-936)
     }
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
+    if (!pool_shape(PATH_MAXLENGTH)) return false;
     PROF_BEGIN2(); init_first_trail(a, true); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
-    while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
+    const uint32_t maxInner = (uint32_t)uni((int)P.MAX_INNER_PATHS);
+    while ((int)(nCur > 0) & (int)((uint32_t)nCur <= maxInner) & (int)((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH) & (int)(uni((int)X.overflow) == 0)) {
       if (nCur == 1) {
-        PROF_BEGIN2(); len += fast_forward(len, stepCounter, PATH_MAXLENGTH, false); PROF_END2(PF_FFWD);
+        PROF_BEGIN2(); len += uni(fast_forward(len, stepCounter, PATH_MAXLENGTH, false)); PROF_END2(PF_FFWD);
         if (X.ffPopped) { X.ffPopped = false; nCur = 0; break; }   // its last step recorded a bridge and ended the Trail
         if (!(stepCounter < PATH_MAXLENGTH)) break;
       }
       PROF_BEGIN2();
-      nCur = step_bridge(nCur, len, stepCounter);
+      nCur = uni(step_bridge(nCur, len, stepCounter));
       PROF_END2(PF_STEPB);
       ++len;
       if (X.tracing && X.trace.steps) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
@@ -1961,13 +2017,14 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
 TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
   PROF_DECL2;
   const DevParams& P = X.P;
-  const uint32_t K = P.K;
-  const AnchorRec* anchors = X.dirRight ? X.ancL : X.ancR;
-  const int nAnch = X.dirRight ? X.nAncL : X.nAncR;
-  const int limit = min(nAnch, (int)P.MAX_START_ANCHORS);
+  const uint32_t K = (uint32_t)uni((int)P.K);
+  const AnchorRec* anchors = uni_ptr(X.dirRight ? X.ancL : X.ancR);
+  const int nAnch = uni(X.dirRight ? X.nAncL : X.nAncR);
+  const int limit = min(nAnch, uni((int)P.MAX_START_ANCHORS));
+  const uint32_t readLen = (uint32_t)uni((int)X.L), maxInner = (uint32_t)uni((int)P.MAX_INNER_PATHS), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
   X.best2[0].have = false; X.best2[1].have = false; X.nEdges = 0;
   for (int s = 0; s < limit; ++s) {
-    const AnchorRec a = anchors[s];
+    const AnchorRec a = uni_anchor(anchors + s);
     const uint32_t whichStart = a.pos;
     uint32_t stepCounter = 0;
     int xdrop = (int)((double)(int)P.CHECK_INTERVAL * P.FAILURE_RATE + 1.0);   // :1031
@@ -1975,8 +2032,8 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     uint32_t gapLen;
     X.refLen = 0;
     if (X.dirRight) {   // TAIL: anchor + suffix(seq, whichStart+K)
-      gapLen = X.L - (whichStart + K);
-      ref_append(whichStart, X.L);
+      gapLen = readLen - (whichStart + K);
+      ref_append(whichStart, readLen);
     } else {            // HEAD: prefix(seq, whichStart) + anchor
       gapLen = whichStart;
       ref_append(whichStart, whichStart + K);
@@ -1984,27 +2041,28 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     }
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
+    if (!pool_shape(PATH_MAXLENGTH)) return false;
     PROF_BEGIN2(); init_first_trail(a, false); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
-    while ((nCur > 0) & ((uint32_t)nCur <= P.MAX_INNER_PATHS) & (stepCounter < PATH_MAXLENGTH) & (X.overflow == 0)) {
+    while ((int)(nCur > 0) & (int)((uint32_t)nCur <= maxInner) & (int)((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH) & (int)(uni((int)X.overflow) == 0)) {
       if (nCur == 1) {
         PROF_BEGIN2();
-        const int ff = fast_forward(len, stepCounter, PATH_MAXLENGTH, true);
+        const int ff = uni(fast_forward(len, stepCounter, PATH_MAXLENGTH, true));
         len += ff;
         PROF_END2(PF_FFWD);
-        if (ff > 0 && (stepCounter % P.CHECK_INTERVAL == 0)) {
+        if (ff > 0 && ((uint32_t)uni((int)stepCounter) % CHECK == 0)) {
           // the fast-forward took the step after which scoring is due (Explorer.cpp:672-686): the one Trail stays
           // where it is (set ia, slot 0) — score it there; five or fewer survivors means no gardening
           PROF_BEGIN2();
-          nCur = score_edges(X.ia, 1, len, xdrop);
+          nCur = uni(score_edges(X.ia, 1, len, xdrop));
           PROF_END2(PF_STEPE);
           continue;
         }
-        if (!(stepCounter < PATH_MAXLENGTH)) break;
+        if (!((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH)) break;
       }
       PROF_BEGIN2();
-      nCur = step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop);
+      nCur = uni(step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop));
       PROF_END2(PF_STEPE);
       ++len;
       if (X.tracing && X.trace.steps)

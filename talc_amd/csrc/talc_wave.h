@@ -16,7 +16,12 @@ namespace talc {
 
 #define WSYNC() __syncthreads()   /* one wave per workgroup: orders the wave's own LDS/global traffic */
 
-TALC_D int lane_id() { return (int)(threadIdx.x & 63u); }
+// the lane's index from the hardware (two VALU ops, no input register): threadIdx.x would have to be carried through
+// every call in a callee-saved vector register
+TALC_D int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// the same, opaque to the optimiser: the copy loops below are unrolled eight-fold, and with a transparent lane index
+// their eight per-lane offsets are hoisted out of whatever loop encloses the (inlined) copy and then spilled
+TALC_D int lane_id_here() { int l = lane_id(); asm volatile("" : "+v"(l)); return l; }
 // whole-wave reductions as DPP VALU ops (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast 15 / 31 across
 // the rows: lane 63 ends up with the result) instead of six ds_bpermute round trips
 #define TALC_WAVE_REDUCE(v, OP, IDENT)                                                                   \
@@ -73,7 +78,7 @@ TALC_D unsigned long long ballot64(bool p) { return __ballot(p); }
 
 // dst[0..n) = src[0..n); both 16-byte aligned, n arbitrary (tail by bytes).
 TALC_D void wave_copy(uint8_t* __restrict__ dst_, const uint8_t* __restrict__ src_, uint32_t n) {
-  const int l = lane_id();
+  const int l = lane_id_here();
   const uint32_t nv = n >> 4;
   gu8 dst = (gu8)dst_; gcu8 src = (gcu8)src_;
   const v4u32 TALC_AS1* s4 = (const v4u32 TALC_AS1*)src;
@@ -84,7 +89,7 @@ TALC_D void wave_copy(uint8_t* __restrict__ dst_, const uint8_t* __restrict__ sr
 // unaligned byte copy, optional reversal of the source range: dst[i] = src[rev ? n-1-i : i]
 TALC_D void wave_copy_bytes(uint8_t* __restrict__ dst_, const uint8_t* __restrict__ src_, uint32_t n, bool rev) {
   gu8 dst = (gu8)dst_; gcu8 src = (gcu8)src_;
-  for (uint32_t i = lane_id(); i < n; i += 64) dst[i] = rev ? src[n - 1 - i] : src[i];
+  for (uint32_t i = (uint32_t)lane_id_here(); i < n; i += 64) dst[i] = rev ? src[n - 1 - i] : src[i];
 }
 
 // ------------------------------------------------------------------ Needleman-Wunsch score
@@ -481,7 +486,7 @@ TALC_D int wfa_select(const int (&F)[NR], const int (&E)[NR], int kmin, int kmax
 // dst[0..n) (LDS, 8-byte aligned) = src[0..n) (global, any alignment): 8 bytes per lane per pass — whole words only, so
 // nothing beyond src[n) is read; the last n % 8 bytes go one by one
 TALC_D void stage_copy(uint8_t TALC_AS3* dst, gcu8 src, int n) {
-  const int l = lane_id();
+  const int l = lane_id_here();
   typedef uint64_t __attribute__((aligned(1))) u64u;
   const int nw = n >> 3;
   for (int w = l; w < nw; w += 64) ((uint64_t TALC_AS3*)dst)[w] = *(const u64u TALC_AS1*)(src + 8 * w);
