@@ -108,40 +108,64 @@ TALC_HD uint64_t table_hash(uint64_t key) { const uint64_t x = key ^ (key >> 29)
 TALC_HD uint64_t table_slot(uint64_t h, uint64_t cap) { return ((h >> 32) * (uint64_t)(uint32_t)cap) >> 32; }
 TALC_HD uint64_t table_home(uint64_t key, uint64_t cap) { return table_slot(table_hash(key), cap); }
 
-// Presence filter, blocked by MINIMIZER: the filter is an array of 64-byte blocks (8 words); a k-mer's block is chosen
-// by the smallest hash among its (K - M + 1) M-mers, its word inside the block and its 3 bits by a hash of the whole
-// k-mer.  Consecutive k-mers of a read share their minimizer for (K - M + 1) / 2 positions on average, so the lanes of
-// a wave that probe consecutive positions ask for a handful of distinct 64-byte lines instead of one each — the
-// probe kernel's cost is random memory requests, not bytes.  Builder (k_build_filter) and prober (k_coverage) share
-// these functions, so the filter has no false negatives by construction; false positives only cost a bucket probe.
+// Presence filter over the stored k-mers: an array of 64-byte blocks (8 words); a k-mer sets / tests 3 bits of one
+// word of one block.  Builder (k_build_filter) and prober (k_coverage) share these functions, so the filter has no
+// false negatives by construction; a false positive only costs a bucket probe.
+//   * The hash is built from 24-bit multiplies (full rate on the vector unit; 32- and 64-bit integer multiplies are
+//     quarter rate, and the probe kernel turned out to be bound by them, not by memory).
+//   * TALC_FILTER_MINIMIZER = 1 chooses the block by the k-mer's minimizer (smallest hash among its K - M + 1 M-mers)
+//     instead of by the k-mer's own hash: consecutive k-mers of a read then share their block for (K - M + 1) / 2
+//     positions on average, so a wave probing consecutive positions touches a handful of 64-byte lines instead of 64.
+//     Measured on config 2 (profiles/r02): the extra M-mer hashing and window minimum cost more than the shared lines
+//     save, so it is off.
+#ifndef TALC_FILTER_MINIMIZER
+#define TALC_FILTER_MINIMIZER 0
+#endif
 #define TALC_MINIMIZER_M 11
+TALC_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
 TALC_HD uint32_t mmer_hash(uint32_t mmer) {   // 22-bit M-mer -> 32-bit hash (0xFFFFFFFF is reserved: "contains N")
-  uint32_t x = mmer * 0x9E3779B1u;
-  x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+  uint32_t x = mul24(mmer, 0x9E3779u) ^ (mmer >> 7);
+  x ^= x >> 15; x = mul24(x, 0x85EBCBu) ^ (x >> 9); x ^= x >> 13;
   return x == 0xFFFFFFFFu ? 0xFFFFFFFEu : x;
 }
-TALC_HD uint64_t filter_block(uint32_t minHash, uint64_t nBlocks) {   // (the minimum of several hashes is not uniform: mix it again)
-  uint32_t x = minHash * 0xC2B2AE3Du; x ^= x >> 16; x *= 0x27D4EB2Fu; x ^= x >> 15;
-  return ((uint64_t)x * nBlocks) >> 32;
-}
-// reference form, from a packed k-mer (first base most significant); the prober takes the same minimum from LDS.
-// M-mers are hashed in little-endian form (base i of the M-mer at bits [2i, 2i+1]), the form they have in the
-// prober's staged window.
+// minimizer hash of a packed k-mer (first base most significant): the prober takes the same minimum from LDS
 TALC_HD uint32_t kmer_min_hash(uint64_t kmer, uint32_t K) {
-  uint64_t x = kmer;   // reverse the 2-bit groups: base j of the k-mer to bits [2j, 2j+1]
-  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-  x = __builtin_bswap64(x) >> (64 - 2 * K);
   uint32_t best = 0xFFFFFFFFu;
   for (uint32_t i = 0; i + TALC_MINIMIZER_M <= K; ++i) {
-    const uint32_t h = mmer_hash((uint32_t)(x >> (2 * i)) & ((1u << (2 * TALC_MINIMIZER_M)) - 1));
+    const uint32_t h = mmer_hash((uint32_t)(kmer >> (2 * (K - TALC_MINIMIZER_M - i))) & ((1u << (2 * TALC_MINIMIZER_M)) - 1));
     best = h < best ? h : best;
   }
   return best;
 }
-TALC_HD uint64_t filter_hash(uint64_t kmer) { return mix64(kmer ^ 0x9E3779B97F4A7C15ULL); }
-TALC_HD uint32_t filter_word(uint64_t h) { return (uint32_t)(h >> 61); }   // word of the block
-TALC_HD uint64_t filter_mask(uint64_t h) { return (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63)) | (1ULL << ((h >> 12) & 63)); }
+// two 32-bit hash words of a k-mer: .x selects the block (unless by minimizer), .y the word and the three bits
+struct FilterHash { uint32_t x, y; };
+TALC_HD FilterHash filter_hash(uint64_t kmer) {
+  const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+  uint32_t a = mul24(lo, 0x9E3779u) + mul24((lo >> 24) | (hi << 8), 0x85EBCBu) + mul24(hi >> 16, 0xC2B2AFu);
+  a ^= a >> 15;
+  uint32_t b = mul24(a, 0x2C1B3Du) ^ (a >> 9);
+  b ^= b >> 13;
+  const uint32_t c = mul24(b, 0x297A2Du) ^ ((a << 7) | (a >> 25)) ^ (b >> 11);
+  FilterHash h; h.x = b; h.y = c;
+  return h;
+}
+TALC_HD uint64_t filter_block(uint32_t h, uint64_t nBlocks) { return ((uint64_t)h * nBlocks) >> 32; }   // nBlocks < 2^32
+TALC_HD uint64_t filter_index(uint64_t kmer, uint32_t K, FilterHash h, uint64_t nBlocks) {
+#if TALC_FILTER_MINIMIZER
+  uint32_t mh = kmer_min_hash(kmer, K);   // (the minimum of several hashes is not uniform: mixed again)
+  mh = mul24(mh, 0xC2B2AFu) ^ (mh >> 11); mh ^= mh >> 15;
+  return filter_block(mh, nBlocks) * 8 + (h.y >> 29);
+#else
+  return filter_block(h.x, nBlocks) * 8 + (h.y >> 29);
+#endif
+}
+TALC_HD uint64_t filter_mask(FilterHash h) { return (1ULL << (h.y & 63)) | (1ULL << ((h.y >> 6) & 63)) | (1ULL << ((h.y >> 12) & 63)); }
 
 // ------------------------------------------------------------------ Dna5 codes
 // reads live in HBM as one byte per base: A=0 C=1 G=2 T=3 N=4 (SeqAn Dna5 ordinals)

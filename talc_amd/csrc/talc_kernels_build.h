@@ -196,8 +196,8 @@ __global__ void k_build_filter(const Bucket* __restrict__ right, uint64_t cap, u
   for (int b = 0; b < 4; ++b) {
     if (r.cnt[b] == 0) continue;
     const uint64_t km = (r.key << 2) | (uint64_t)b;
-    const uint64_t h = filter_hash(km);
-    atomicOr(&filter[filter_block(kmer_min_hash(km, K), nBlocks) * 8 + filter_word(h)], (unsigned long long)filter_mask(h));
+    const FilterHash h = filter_hash(km);
+    atomicOr(&filter[filter_index(km, K, h, nBlocks)], (unsigned long long)filter_mask(h));
   }
 }
 

@@ -90,41 +90,33 @@ __global__ void k_encode(const uint8_t* __restrict__ raw, uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------ coverage (the k-mer probe kernel)
-// One block per tile of up to COV_TILE consecutive k-mer positions of ONE read.
-//  1. the tile's base window (COV_TILE + K - 1 codes) is staged into LDS as 2-bit packed words
-//     plus an N bitmap (coalesced byte loads, 16 bases per thread per pass);
-//  2. the hash of every M-mer of the window goes to LDS (one per thread per pass): a k-mer's minimizer hash is the
-//     minimum of K - M + 1 consecutive entries, and it selects the k-mer's 64-byte block of the presence filter —
-//     thread t takes positions t, t+256, ..., so the lanes of a wave probe consecutive positions, which share their
-//     minimizer in runs: a wave's filter probes touch a handful of distinct 64-byte lines instead of 64;
-//  3. the k-mer itself is two LDS words funnel-shifted; only if the filter says "maybe" (7-9 % of a noisy read's
-//     positions) is the 32-byte bucket of its (K-1)-prefix probed in HBM, and for a k-mer that is in the table the
-//     two buckets that give its out-degrees;
-//  4. (count, colour | degrees) is written as one 8-byte store per k-mer, coalesced across the wave;
-//  5. #{count > MIN_COUNT} (Read.cpp:190) is reduced per block and added to the read's counter.
+// One block per tile of up to COV_TILE consecutive k-mer positions of ONE read, in two phases:
+//  A. the tile's base window (COV_TILE + K - 1 codes) is staged into LDS as 2-bit packed words (first base most
+//     significant, so a k-mer is one funnel shift away from its table form) plus an N bitmap; thread t takes positions
+//     t, t+256, ...: k-mer, presence-filter test (one 8-byte word of a cache-resident array), and either an 8-byte
+//     (0, 0) store — coalesced across the wave — or, for the 7-9 % that may be in the table, an entry in an LDS queue;
+//  B. the queue is worked off with every lane busy: the 32-byte bucket of the k-mer's (K-1)-prefix (the only random HBM
+//     access of a lookup) and, for a k-mer that is in the table, the two buckets that give its out-degrees; the result
+//     overwrites the position's (0, 0).  Doing this inside phase A would run the whole probe sequence — three table
+//     hashes with 64-bit multiplies — on every iteration of every wave for one lane in twelve.
+//  #{count > MIN_COUNT} (Read.cpp:190) is reduced per block and added to the read's counter.
 #define COV_TILE 2048
 #define COV_THREADS 256
-
-// the 2-bit groups of x reversed (group g <-> group 31 - g)
-TALC_HD uint64_t rev2bit64(uint64_t x) {
-  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-#if defined(__HIPCC__) || defined(__GNUC__)
-  return __builtin_bswap64(x);
-#endif
-}
 
 __global__ void __launch_bounds__(COV_THREADS)
 k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
            const uint64_t* __restrict__ koff, const uint32_t* __restrict__ tile_read,
            const uint32_t* __restrict__ tile_start, uint2* __restrict__ cov, int32_t* __restrict__ n_in,
            uint32_t min_count) {
-  __shared__ uint64_t s_pack[(COV_TILE + 64) / 32 + 2];
-  __shared__ uint64_t s_nmask[(COV_TILE + 64) / 64 + 2];
-  __shared__ uint32_t s_mh[COV_TILE + 64];          // hash of the M-mer starting at each window position
+  __shared__ uint64_t s_pack[(COV_TILE + 64) / 32 + 3];   // base i of the window at bits [63 - 2 (i % 32) - 1, 63 - 2 (i % 32)] of word i / 32
+  __shared__ uint64_t s_nmask[(COV_TILE + 64) / 64 + 2];  // bit (i % 64) of word i / 64: base i is N
+#if TALC_FILTER_MINIMIZER
+  __shared__ uint32_t s_mh[COV_TILE + 64];                // hash of the M-mer starting at each window position
+#endif
+  __shared__ uint16_t s_queue[COV_TILE];                  // positions whose k-mer passed the filter
+  __shared__ uint32_t s_qn;
   __shared__ int s_nin;
   const uint32_t K = T.k;
-  constexpr uint32_t M = TALC_MINIMIZER_M;
   const uint32_t r = tile_read[blockIdx.x];
   const uint32_t p0 = tile_start[blockIdx.x];
   const uint64_t rb = offsets[r];
@@ -134,77 +126,112 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   const uint32_t wlen = cnt + K - 1;                  // bases in the window
   const uint8_t TALC_AS1* src = (const uint8_t TALC_AS1*)(codes + rb + p0);
 
-  if (threadIdx.x == 0) s_nin = 0;
-  // stage: 16 bases -> one u32 of 2-bit codes + 16 N bits, per thread per pass
+  if (threadIdx.x == 0) { s_nin = 0; s_qn = 0; }
+  // stage: 16 bases -> one u32 of 2-bit codes (first base in the top bits) + 16 N bits, per thread per pass
   {
     uint32_t* pk32 = reinterpret_cast<uint32_t*>(s_pack);
     uint16_t* nm16 = reinterpret_cast<uint16_t*>(s_nmask);
     const uint32_t ngroups = (wlen + 15) / 16;
-    for (uint32_t g = threadIdx.x; g < ngroups; g += COV_THREADS) {
+    for (uint32_t g = threadIdx.x; g < ngroups + 6; g += COV_THREADS) {   // (+ zeroed guard groups for the funnel shifts)
       uint32_t w = 0, nm = 0;
       const uint32_t base = g * 16;
+      if (g < ngroups) {
+        // 16 codes as two unaligned 8-byte loads (whole words only inside the window; the last group byte by byte)
+        typedef uint64_t __attribute__((aligned(1))) u64u;
+        uint64_t lo8 = 0, hi8 = 0;
+        if (base + 16 <= wlen) {
+          lo8 = *(const u64u TALC_AS1*)(src + base);
+          hi8 = *(const u64u TALC_AS1*)(src + base + 8);
+        } else {
+          for (uint32_t j = 0; j < 16 && base + j < wlen; ++j) {
+            const uint64_t c = (uint64_t)src[base + j];
+            if (j < 8) lo8 |= c << (8 * j); else hi8 |= c << (8 * (j - 8));
+          }
+        }
 #pragma unroll
-      for (uint32_t j = 0; j < 16; ++j) {
-        uint32_t c = (base + j < wlen) ? (uint32_t)src[base + j] : 0u;
-        nm |= (c > 3u ? 1u : 0u) << j;
-        w |= (c & 3u) << (2 * j);   // base j of the group at bits [2j, 2j+1]: little-endian within the word
+        for (uint32_t j = 0; j < 16; ++j) {
+          const uint32_t c = (uint32_t)(((j < 8) ? (lo8 >> (8 * j)) : (hi8 >> (8 * (j - 8)))) & 0xFFu);
+          nm |= (c > 3u ? 1u : 0u) << j;
+          w |= (c & 3u) << (30 - 2 * j);
+        }
       }
-      pk32[g] = w;
+      pk32[g ^ 1] = w;          // even group = high half of its 64-bit word
       nm16[g] = (uint16_t)nm;
     }
-    // zero the guard words so that the funnel shifts below never read uninitialised LDS
-    if (threadIdx.x == 0) { pk32[ngroups] = 0; pk32[ngroups + 1] = 0; pk32[ngroups + 2] = 0; pk32[ngroups + 3] = 0;
-                            nm16[ngroups] = 0; nm16[ngroups + 1] = 0; nm16[ngroups + 2] = 0; nm16[ngroups + 3] = 0; }
   }
   __syncthreads();
 
-  // little-endian window bits [2q, 2q + 64) and N bits [q, q + 64)
-  auto window = [&](uint32_t q, uint64_t& le, uint64_t& nb) {
-    const uint32_t bit = 2 * q, w = bit >> 6, sh = bit & 63;
-    const uint64_t lo = s_pack[w], hi = s_pack[w + 1];
-    le = (sh == 0) ? lo : ((lo >> sh) | (hi << (64 - sh)));
+  // the 64 window bits that start with base q (first base most significant), and the N bits [q, q + 64)
+  auto window = [&](uint32_t q) -> uint64_t {
+    const uint32_t w = q >> 5, sh = 2 * (q & 31);
+    const uint64_t hi = s_pack[w], lo = s_pack[w + 1];
+    return (sh == 0) ? hi : ((hi << sh) | (lo >> (64 - sh)));
+  };
+  auto nbits = [&](uint32_t q) -> uint64_t {
     const uint32_t nw = q >> 6, nsh = q & 63;
     const uint64_t nlo = s_nmask[nw], nhi = s_nmask[nw + 1];
-    nb = (nsh == 0) ? nlo : ((nlo >> nsh) | (nhi << (64 - nsh)));
+    return (nsh == 0) ? nlo : ((nlo >> nsh) | (nhi << (64 - nsh)));
   };
-  // M-mer hashes of the window (an M-mer with an N never is the minimum: such k-mers are not looked up at all)
+#if TALC_FILTER_MINIMIZER
+  constexpr uint32_t M = TALC_MINIMIZER_M;
   const uint32_t nmm = wlen - M + 1;                 // K >= 18 > M
-  for (uint32_t q = threadIdx.x; q < nmm; q += COV_THREADS) {
-    uint64_t le, nb;
-    window(q, le, nb);
-    const uint32_t mm = (uint32_t)le & ((1u << (2 * M)) - 1);   // base q+i at bits [2i, 2i+1]
-    s_mh[q] = (nb & ((1ull << M) - 1)) ? 0xFFFFFFFFu : mmer_hash(mm);
-  }
+  for (uint32_t q = threadIdx.x; q < nmm; q += COV_THREADS)
+    s_mh[q] = (nbits(q) & ((1ull << M) - 1)) ? 0xFFFFFFFFu : mmer_hash((uint32_t)(window(q) >> (64 - 2 * M)));
   __syncthreads();
+  const uint32_t nwin = K - M + 1;                   // M-mers per k-mer
+#endif
 
-  const uint64_t kbits = 2ull * K;
-  const uint64_t kmaskLE = (K >= 32) ? ~0ULL : ((1ULL << kbits) - 1);
+  const uint32_t kshift = 64 - 2 * K;
+  const uint64_t nkmask = (K >= 64) ? ~0ULL : ((1ULL << K) - 1);
   const uint64_t nBlocks = T.filterWords >> 3;
   const uint64_t TALC_AS1* filter = (const uint64_t TALC_AS1*)T.filter;
-  const uint32_t nwin = K - M + 1;                   // M-mers per k-mer
-  int local_in = 0;
-  uint2* out = cov + koff[r] + p0;
-  for (uint32_t p = threadIdx.x; p < cnt; p += COV_THREADS) {
-    uint64_t le, nb;
-    window(p, le, nb);
-    le &= kmaskLE;  // base p+i at bits [2i, 2i+1]
-    nb &= (K >= 64) ? ~0ULL : ((1ULL << K) - 1);   // any N among bases [p, p+K)
-    // the table's big-endian packing (first base most significant): reverse the 2-bit groups
-    const uint64_t kmer = rev2bit64(le) >> (64 - kbits);
-    uint32_t c = 0, j = 0;
-    bool maybe = (nb == 0);
-    if (maybe && filter) {   // presence filter first: one 8-byte word of the minimizer's 64-byte block
-      uint32_t mh = s_mh[p];
-      for (uint32_t i = 1; i < nwin; ++i) mh = min(mh, s_mh[p + i]);
-      const uint64_t h = filter_hash(kmer), m = filter_mask(h);
-      maybe = (filter[filter_block(mh, nBlocks) * 8 + filter_word(h)] & m) == m;
+  v2u32 TALC_AS1* out = (v2u32 TALC_AS1*)(cov + koff[r] + p0);
+  // ---- phase A
+  for (uint32_t pb = 0; pb < cnt; pb += COV_THREADS) {
+    const uint32_t p = pb + threadIdx.x;
+    bool maybe = false;
+    if (p < cnt) {
+      maybe = (nbits(p) & nkmask) == 0;          // no N among bases [p, p+K)
+      if (maybe && filter) {
+        const uint64_t kmer = window(p) >> kshift;
+        const FilterHash h = filter_hash(kmer);
+        const uint64_t m = filter_mask(h);
+#if TALC_FILTER_MINIMIZER
+        uint32_t mh = s_mh[p];
+        for (uint32_t i = 1; i < nwin; ++i) mh = min(mh, s_mh[p + i]);
+        mh = mul24(mh, 0xC2B2AFu) ^ (mh >> 11); mh ^= mh >> 15;
+        const uint64_t idx = filter_block(mh, nBlocks) * 8 + (h.y >> 29);
+#else
+        const uint64_t idx = filter_block(h.x, nBlocks) * 8 + (h.y >> 29);
+#endif
+        maybe = (filter[idx] & m) == m;
+      }
+      if (!maybe) out[p] = v2u32{0u, 0u};
     }
-    if (maybe) dev_get_count(T, kmer, c, j);
+    // queue the survivors: one LDS atomic per wave
+    const unsigned long long bal = __ballot(maybe);
+    if (bal) {
+      const uint32_t lane = threadIdx.x & 63u;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&s_qn, (uint32_t)__popcll(bal));
+      base = (uint32_t)__shfl((int)base, 0, 64);
+      if (maybe) s_queue[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)p;
+    }
+  }
+  __syncthreads();
+  // ---- phase B
+  const uint32_t qn = s_qn;
+  const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
+  int local_in = 0;
+  for (uint32_t qi = threadIdx.x; qi < qn; qi += COV_THREADS) {
+    const uint32_t p = s_queue[qi];
+    const uint64_t kmer = window(p) >> kshift;
+    uint32_t c = 0, j = 0;
+    dev_get_count(T, kmer, c, j);
     if (c != 0) {
       // a k-mer of the table: its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this
       // MIN_COUNT) ride in the colour word's upper half — the anchor search asks for them position by position
       // (Explorer.cpp:449,515) and would otherwise probe, one dependent access at a time
-      const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
       BucketRegs br;
       uint32_t dR = 0, dL = 0;
       if (probe_bucket(T.right, T.capacity, kmer & m1, br))
@@ -213,7 +240,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
         dL = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
       j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
     }
-    out[p] = make_uint2(c, j);
+    out[p] = v2u32{c, j};
     local_in += (c > min_count) ? 1 : 0;
   }
   // block reduction of local_in
