@@ -211,6 +211,13 @@ uint64_t talc_batch_corrected_bytes(const talc_batch* b);
 int talc_batch_fetch_corrected(talc_ctx* c, talc_batch* b, char* out, uint64_t out_capacity,
                                uint64_t* out_offsets, int32_t* status);
 
+/* The rows Read::outputBasicReadStats (Read.cpp:418-433) appends to <o>.stats_basics.txt — the reference has the call
+ * commented out (main.cpp:305), so its file only ever holds the header; the numbers exist on the device anyway.
+ * stats5[5 r ..] = {row written (length > K, main.cpp:262), raw length, sum over the IN regions of end - start + 1 as
+ * they stand after the read's last step (Read.cpp:423), number of IN regions, length of the correction (0 unless the
+ * read was corrected)}.  Valid after talc_batch_correct. */
+int talc_batch_fetch_read_stats(talc_ctx* c, talc_batch* b, int64_t* stats5);
+
 /* Same records, copied device-to-device into a caller-owned DEVICE buffer (e.g. a tensor that
  * is then gathered over RCCL); out_offsets/status are host arrays and may be NULL. */
 int talc_batch_copy_corrected_device(talc_ctx* c, talc_batch* b, void* device_out, uint64_t out_capacity,

@@ -198,6 +198,29 @@ int orc_correct_batch(void* t, const orc_params* p, const char* bases, const uin
   return 0;
 }
 
+// the same with the rows of Read::outputBasicReadStats (Read.cpp:418-433; call commented out at main.cpp:305):
+// stats5[5 r ..] = {row written (L > K), raw length, span of the IN regions, number of IN regions, corrected length}
+int orc_correct_batch_stats(void* t, const orc_params* p, const char* bases, const uint64_t* offsets, uint32_t n,
+                            char* out, uint64_t out_cap, uint64_t* out_offsets, int32_t* status, int nthreads, int64_t* stats5) {
+  Ctx C; C.P = toParams(p); C.dBG = (Table*)t;
+  std::vector<TSeq> seqs(n);
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+  for (long r = 0; r < (long)n; ++r) {
+    seqs[r] = toDna5(std::string(bases + offsets[r], offsets[r + 1] - offsets[r]));
+    BasicReadStats bs;
+    status[r] = (int32_t)correctOneRead(C, "", seqs[r], nullptr, &bs);
+    stats5[5 * r] = bs.written ? 1 : 0; stats5[5 * r + 1] = bs.rawLength; stats5[5 * r + 2] = bs.nbInKmersBefore;
+    stats5[5 * r + 3] = bs.nbSReg; stats5[5 * r + 4] = bs.corrLength;
+  }
+  uint64_t pos = 0;
+  for (uint32_t r = 0; r < n; ++r) { out_offsets[r] = pos; pos += seqs[r].size(); }
+  out_offsets[n] = pos;
+  if (pos > out_cap) return -1;
+  for (uint32_t r = 0; r < n; ++r) memcpy(out + out_offsets[r], seqs[r].data(), seqs[r].size());
+  return 0;
+}
+
 // textual trace of one read (regions, anchors, per-gap results) for divergence hunting
 int64_t orc_trace_read(void* t, const orc_params* p, const char* bases, uint64_t len, int steps, char* buf,
                        uint64_t cap) {

@@ -1594,23 +1594,37 @@ void Read::correct2() {  // Read.cpp:336-386
   updateCorrSeq();
 }
 
+// Read.cpp:418-433 (Read::outputBasicReadStats) without the file: the four numbers of a row
+void Read::basicReadStats(long& rawLength, unsigned int& nbInKmersBefore, int& nbSReg, long& corrLength) const {
+  nbInKmersBefore = 0;
+  if (!m_InKmersPositions.empty())
+    for (unsigned int i = 0; i < m_InKmersPositions.size(); i++)
+      nbInKmersBefore += std::get<1>(m_InKmersPositions[i]) - std::get<0>(m_InKmersPositions[i]) + 1;   // :423
+  nbSReg = (int)m_InKmersPositions.size();                                                                // :424
+  rawLength = (long)m_sequence.size();                                                                    // :428
+  corrLength = (long)m_correction.size();                                                                 // :431
+}
+
 // main.cpp:247-308, one iteration
-ReadStatus correctOneRead(const Ctx& C, const std::string& id, TSeq& seq, Trace* trace) {
+ReadStatus correctOneRead(const Ctx& C, const std::string& id, TSeq& seq, Trace* trace, BasicReadStats* stats) {
   if (C.P.gp_reverse) seq = reverseComplement(seq);  // :253 (before any length test)
   Read myLRead(C, id, seq, trace);
+  ReadStatus rs = RS_SKIPPED_SHORT;
   if (myLRead.getLength() > (int)C.P.K) {           // :262
     if (myLRead.reCoverage()) {                     // :267
       if (myLRead.defineStructure2()) {             // :272
         myLRead.correct2();                         // :277
         seq = myLRead.getCorrSeq();                 // :285
         if (C.P.gp_reverse) seq = reverseComplement(seq);  // :286
-        return RS_CORRECTED;
-      }
-      return RS_NO_STRUCTURE;                       // :290
+        rs = RS_CORRECTED;
+      } else rs = RS_NO_STRUCTURE;                  // :290
+    } else rs = RS_NO_SOLID_KMER;                   // :294
+    if (stats) {                                    // :305 (commented out in the reference)
+      stats->written = true;
+      myLRead.basicReadStats(stats->rawLength, stats->nbInKmersBefore, stats->nbSReg, stats->corrLength);
     }
-    return RS_NO_SOLID_KMER;                        // :294
   }
-  return RS_SKIPPED_SHORT;
+  return rs;
 }
 
 }  // namespace talc_oracle

@@ -325,6 +325,9 @@ class Read {
   const std::vector<kmerStretch>& getRegions() const { return m_InKmersPositions; }
   double getPriorNoise() const { return m_priorLambda_noise; }
   int nbInKmers() const { return m_nbInKmers; }
+  // the row Read::outputBasicReadStats appends to <o>.stats_basics.txt (Read.cpp:418-433): raw length, span of the
+  // IN regions as they stand, their number, length of the correction (the name is the caller's)
+  void basicReadStats(long& rawLength, unsigned int& nbInKmersBefore, int& nbSReg, long& corrLength) const;
 
  private:
   bool setInitialStructure();                                                                // :214
@@ -350,7 +353,10 @@ class Read {
 // main.cpp:247-308 loop body for one read.  `seq` is modified in place exactly like
 // mySeqs[r] in the reference (including the -rev quirk: reads that are not corrected
 // stay reverse-complemented, main.cpp:253 vs :286).
-ReadStatus correctOneRead(const Ctx& C, const std::string& id, TSeq& seq, Trace* trace = nullptr);
+struct BasicReadStats { bool written = false; long rawLength = 0; unsigned int nbInKmersBefore = 0; int nbSReg = 0; long corrLength = 0; };
+// stats (optional): what the commented-out call at main.cpp:305 would have appended for this read — it sits inside
+// `if (getLength() > K)`, after the try block, so every read longer than K gets a row, corrected or not.
+ReadStatus correctOneRead(const Ctx& C, const std::string& id, TSeq& seq, Trace* trace = nullptr, BasicReadStats* stats = nullptr);
 
 // ---- I/O restatements (io.cpp + SeqAn semantics) ----
 TSeq toDna5(const std::string& raw);                       // Dna5 conversion: acgtn -> upper, others -> N

@@ -25,7 +25,7 @@ static void usage() {
   std::cerr << "talc_ref <reads.fa|fq> -k K -SR dump [-j junctions] [-o prefix] [-t threads] [-rev]\n"
                "  [--MIN_INNER_SCORE f] [--MIN_BORDER_SCORE f] [--MIN_COUNT n] [--SR_ERROR_RATE f]\n"
                "  [--WINDOW_SIZE n] [--MAX_NB_BRANCHES n] [--ALPHA_FOR_PRED f] [-qm memory|jellyfish2]\n"
-               "  [--table-backend map|flat]\n";
+               "  [--table-backend map|flat] [--read-stats]\n";
 }
 
 template <typename T>
@@ -34,6 +34,7 @@ static void printNum(std::ostream& os, T v) { os << v; }
 int main(int argc, const char* argv[]) {
   Params P;
   std::string seqFile, outPrefix = "out", queryMode = "memory", dump, jdump, backend = "map";
+  bool readStats = false;
   bool haveK = false, haveSR = false, useJ = false;
   int nthreads = 1;
   auto need = [&](int& i) -> const char* {
@@ -62,6 +63,7 @@ int main(int argc, const char* argv[]) {
     else if (a == "--DEBUG_MODE" || a == "-DEBUG_MODE") need(i);
     else if (a == "-rev" || a == "--reverse") P.gp_reverse = true;
     else if (a == "--table-backend") backend = need(i);
+    else if (a == "--read-stats") readStats = true;   // the call the reference has commented out at main.cpp:305
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else if (a == "--version") { std::cout << "TALC version: 1.01\nLast update: September 2019\n"; return 0; }
     else if (!a.empty() && a[0] == '-') { std::cerr << "talc_ref: unknown option " << a << "\n"; return 1; }
@@ -121,10 +123,17 @@ int main(int argc, const char* argv[]) {
   }
   Ctx C; C.P = P; C.dBG = &table;
   std::vector<int> status(ids.size(), 0);
+  std::vector<BasicReadStats> bstats(ids.size());
   omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(dynamic)
-  for (long r = 0; r < (long)ids.size(); r++) status[r] = (int)correctOneRead(C, ids[r], seqs[r]);
+  for (long r = 0; r < (long)ids.size(); r++) status[r] = (int)correctOneRead(C, ids[r], seqs[r], nullptr, &bstats[r]);
   auto t2 = std::chrono::steady_clock::now();
+  if (readStats) {   // Read.cpp:425-431, in input order
+    std::ofstream o(statFile, std::ios_base::app);
+    for (size_t r = 0; r < ids.size(); ++r)
+      if (bstats[r].written)
+        o << "\n" << ids[r] << "\t" << bstats[r].rawLength << "\t" << bstats[r].nbInKmersBefore << "\t" << bstats[r].nbSReg << "\t" << bstats[r].corrLength;
+  }
   for (size_t r = 0; r < ids.size(); ++r) {  // main.cpp:290,294 (input order)
     if (status[r] == RS_NO_STRUCTURE) throwToLog(ids[r], "Unable to define convenient structure.", logFile);
     else if (status[r] == RS_NO_SOLID_KMER) throwToLog(ids[r], "No solid kmer could be found.", logFile);

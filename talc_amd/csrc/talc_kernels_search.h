@@ -42,6 +42,8 @@ struct ReadState {
   double lambda;        // m_priorLambda_noise (Read.cpp:268-269)
   uint32_t outLen;      // corrected length in codes (growth of the read's out slot)
   uint32_t overflow;    // OVF_* bits: scratch exhausted, read left unchanged
+  uint32_t inSpan;      // sum over the IN regions of (end - start + 1), as they stand (Read.cpp:423: the stats row)
+  uint32_t pad_;
 };
 
 __host__ __device__ inline uint64_t out_capacity_for(uint64_t L) { return 4 * L + 1024; }
@@ -253,7 +255,7 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   const uint8_t* read = codes + offsets[r];
   const uint32_t L = (uint32_t)(offsets[r + 1] - offsets[r]);
   ReadState st;
-  st.status = TALC_READ_CORRECTED; st.nRegions = 0; st.lambda = (double)MINC; st.outLen = 0; st.overflow = 0;
+  st.status = TALC_READ_CORRECTED; st.nRegions = 0; st.lambda = (double)MINC; st.outLen = 0; st.overflow = 0; st.inSpan = 0; st.pad_ = 0;
   if (!(L > K)) { st.status = TALC_READ_SKIPPED_SHORT; if (l == 0) state[r] = st; return; }      // main.cpp:262
   if (!(n_in[r] > 0)) { st.status = TALC_READ_NO_SOLID_KMER; if (l == 0) state[r] = st; return; }  // Read.cpp:194
   const uint32_t n = L - K + 1;
@@ -423,6 +425,11 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     checok &= (len == (unsigned long long)L);
   }
   st.nRegions = Rfinal;
+  {   // Read.cpp:423 on the regions as defineStructure2 leaves them (k_search redoes it for the reads it corrects)
+    unsigned long long part = 0;
+    for (uint32_t i = l; i < Rfinal; i += 64) part += (unsigned long long)regE[i] - regS[i] + 1;
+    st.inSpan = (uint32_t)wave_sum_u64(part);
+  }
   if (!checok) st.status = TALC_READ_NO_STRUCTURE;   // main.cpp:290
   if (l == 0) state[r] = st;
   if (trace.recs && r == traceRead && l == 0) {
@@ -2292,7 +2299,12 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       if (tailCorr) { wave_copy_bytes(out + pos, X.weak + tailOff, tailCLen, false); pos += tailCLen; }
       else { wave_copy_bytes(out + pos, X.read + (L - tailLen), tailLen, false); pos += tailLen; }
     }
-    if (l == 0) state[r].outLen = pos;
+    {   // Read.cpp:423 on the regions as correct2 leaves them
+      unsigned long long part = 0;
+      for (uint32_t i = l; i < R; i += 64) part += (unsigned long long)X.regE[i] - X.regS[i] + 1;
+      const uint32_t span = (uint32_t)wave_sum_u64(part);
+      if (l == 0) { state[r].outLen = pos; state[r].inSpan = span; }
+    }
     PROF_END2(PF_ASSEMBLE);
   }
   if (l == 0) {

@@ -9,6 +9,8 @@
 // Options = the reference's table (same names, defaults, ranges), plus:
 //   --gpus N         number of GPUs to use (default: all visible)
 //   --batch-reads N  reads per device batch (default 200000)
+//   --read-stats     append the per-read rows of Read::outputBasicReadStats (Read.cpp:418-433) to <o>.stats_basics.txt
+//                    (the reference has that call commented out, main.cpp:305, and only ever writes the header)
 //   -k accepts 18..31 (the reference stops at 30, main.cpp:115-116; 31 still fits 62 bits)
 // -t/--num_threads is accepted and ignored (the parallelism is on the device).
 // Differences, all documented in INTEGRATION.md: stdout carries the [TALC] banners but none of
@@ -40,6 +42,7 @@ struct Options {
   int gpus = -1;
   int nthreads = 1;
   uint32_t batchReads = 200000;
+  bool readStats = false;
 };
 
 void usage(FILE* f) {
@@ -64,6 +67,7 @@ void usage(FILE* f) {
           "  -rev, --reverse             reverse-complement the long reads before correction\n"
           "  --gpus INT                  GPUs to use (default: all)\n"
           "  --batch-reads INT           reads per device batch (default 200000)\n"
+          "  --read-stats                append per-read rows to <o>.stats_basics.txt (Read.cpp:418-433)\n"
           "  -h, --help / --version\n");
 }
 
@@ -110,6 +114,7 @@ Options parse(int argc, const char** argv) {
     else if (is(a, "rev", "reverse")) o.p.reverse = 1;
     else if (a == "--gpus") { o.gpus = (int)num(need(i), "gpus"); range(o.gpus, 1, 64, "gpus"); }
     else if (a == "--batch-reads") { double v = num(need(i), "batch-reads"); range(v, 1, 4e9, "batch-reads"); o.batchReads = (uint32_t)v; }
+    else if (a == "--read-stats") o.readStats = true;
     else if (a == "-h" || a == "--help") { usage(stdout); exit(0); }
     else if (a == "--version") { std::cout << "talc version: 1.01\nLast update: September 2019\n"; exit(0); }
     else if (a.size() > 1 && a[0] == '-') parse_error("unknown option: " + a);
@@ -209,13 +214,42 @@ class SeqReader {
 };
 
 // One batch of reads on its way through the pipeline: read -> corrected on a device -> written, in input order.
+// a growable page-locked host buffer (talc_pinned_alloc): the reads of a batch are parsed straight into it and the
+// corrected records come back into another one, so both directions are DMA transfers that run beside the kernels of
+// the GPU's other worker; each worker keeps its two buffers for the whole run
+struct PinnedBuf {
+  char* p = nullptr;
+  size_t cap = 0, len = 0;
+  bool pinned = false;
+  void release() { if (pinned) talc_pinned_free(p); else free(p); p = nullptr; }
+  ~PinnedBuf() { release(); }
+  bool reserve(size_t n) {
+    if (n <= cap) return true;
+    size_t nc = std::max<size_t>(n, std::max<size_t>(cap * 2, 1u << 20));
+    bool pin = true;
+    char* q = (char*)talc_pinned_alloc(nc);
+    if (!q) { q = (char*)malloc(nc); pin = false; }   // (no GPU / no page-locked memory left: pageable works too, only slower)
+    if (!q) return false;
+    if (len) memcpy(q, p, len);
+    release();
+    p = q; cap = nc; pinned = pin;
+    return true;
+  }
+  bool append(const std::string& s) {
+    if (!reserve(len + s.size())) return false;
+    memcpy(p + len, s.data(), s.size());
+    len += s.size();
+    return true;
+  }
+};
+
 struct Chunk {
   uint64_t index = 0;
   std::vector<std::string> ids;
-  std::string bases;
-  std::vector<uint64_t> offsets{0};
+  std::vector<uint64_t> offsets{0};     // into the worker's input buffer
   std::vector<std::string> out;
   std::vector<int32_t> status;
+  std::vector<int64_t> stats;           // 5 per read (--read-stats)
 };
 
 double secs(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -304,27 +338,28 @@ int main(int argc, const char** argv) {
   // transfers overlap the other's kernels), and written strictly in input order; at most one batch per worker is
   // in memory.  Replaces the load-everything / OpenMP loop / write-everything of main.cpp:209-310.
   SeqReader reader(o.seqFile);
+  std::atomic<bool> failed{false};
   std::mutex rdMu, wrMu;
   uint64_t nextIndex = 0, nextToWrite = 0, basesTotal = 0;
   std::map<uint64_t, std::unique_ptr<Chunk>> finished;
-  std::ofstream lf;
-  std::atomic<bool> failed{false};
+  std::ofstream lf, sf;
   std::mutex failMu;
   std::string failMsg;
   std::atomic<uint64_t> readErrors{0};
   auto setFailed = [&]() { std::lock_guard<std::mutex> g(failMu); if (!failed) failMsg = talc_last_error(); failed = true; };
-  auto readChunk = [&]() -> std::unique_ptr<Chunk> {
+  auto readChunk = [&](PinnedBuf& in) -> std::unique_ptr<Chunk> {
     std::lock_guard<std::mutex> g(rdMu);
     std::unique_ptr<Chunk> c(new Chunk());
     std::string id, seq;
+    in.len = 0;
     while (c->ids.size() < o.batchReads && reader.next(id, seq)) {
       c->ids.push_back(id);
-      c->bases += seq;
-      c->offsets.push_back(c->bases.size());
+      if (!in.append(seq)) { failed = true; return nullptr; }
+      c->offsets.push_back(in.len);
     }
     if (c->ids.empty()) return nullptr;
     c->index = nextIndex++;
-    basesTotal += c->bases.size();
+    basesTotal += in.len;
     return c;
   };
   auto writeReady = [&](std::unique_ptr<Chunk> c) {   // io.cpp:50-75 + SeqFileOut FASTA writer, io.cpp:105-111 log lines
@@ -342,6 +377,10 @@ int main(int argc, const char** argv) {
           if (!lf.is_open()) lf.open(logFile, std::ios_base::app);
           lf << "[Read: " << k.ids[r] << " ]: " << msg << std::endl;
         }
+        if (o.readStats && k.stats.size() == 5 * k.ids.size() && k.stats[5 * r]) {   // Read.cpp:425-431
+          if (!sf.is_open()) sf.open(statFile, std::ios_base::app);
+          sf << "\n" << k.ids[r] << "\t" << k.stats[5 * r + 1] << "\t" << k.stats[5 * r + 2] << "\t" << k.stats[5 * r + 3] << "\t" << k.stats[5 * r + 4];
+        }
         of << '>' << k.ids[r] << '\n';   // '>' id, sequence wrapped at 70 columns
         const std::string& q = k.out[r];
         for (size_t p = 0; p < q.size(); p += 70) { of.write(q.data() + p, (std::streamsize)std::min<size_t>(70, q.size() - p)); of.put('\n'); }
@@ -350,12 +389,12 @@ int main(int argc, const char** argv) {
       ++nextToWrite;
     }
   };
-  auto passThrough = [&](Chunk& c) {
+  auto passThrough = [&](Chunk& c, const PinnedBuf& in) {
     // no table at all: pass-through with the reference's statuses (Dna5 conversion / -rev still apply)
     const size_t n = c.ids.size();
     c.out.resize(n); c.status.assign(n, TALC_READ_SKIPPED_SHORT);
     for (size_t r = 0; r < n; ++r) {
-      std::string q = c.bases.substr(c.offsets[r], c.offsets[r + 1] - c.offsets[r]);
+      std::string q(in.p + c.offsets[r], c.offsets[r + 1] - c.offsets[r]);
       for (auto& ch : q) { ch = (ch == 'a' || ch == 'A') ? 'A' : (ch == 'c' || ch == 'C') ? 'C' : (ch == 'g' || ch == 'G') ? 'G' : (ch == 't' || ch == 'T') ? 'T' : 'N'; }
       if (o.p.reverse) {
         std::string rcs(q.size(), 'N');
@@ -363,31 +402,34 @@ int main(int argc, const char** argv) {
         q = rcs;
       }
       c.status[r] = q.size() > o.p.k ? TALC_READ_NO_SOLID_KMER : TALC_READ_SKIPPED_SHORT;
+      if (o.readStats) { c.stats.resize(5 * n, 0); if (q.size() > o.p.k) { c.stats[5 * r] = 1; c.stats[5 * r + 1] = (int64_t)q.size(); } }
       c.out[r] = q;
     }
   };
   auto worker = [&](int device) {
     talc_ctx* ctx = nullptr;
     if (device >= 0 && talc_ctx_create(table, &o.p, device, &ctx) != TALC_OK) { setFailed(); return; }
+    PinnedBuf in, outb;
     while (!failed) {
-      std::unique_ptr<Chunk> c = readChunk();
+      std::unique_ptr<Chunk> c = readChunk(in);
       if (!c) break;
       if (device < 0) {
-        passThrough(*c);
+        passThrough(*c, in);
       } else {
         const uint32_t n = (uint32_t)c->ids.size();
         c->out.resize(n); c->status.assign(n, TALC_READ_SKIPPED_SHORT);
         talc_batch* b = nullptr;
-        if (talc_batch_create(ctx, c->bases.data(), c->offsets.data(), n, &b) != TALC_OK) { setFailed(); break; }
+        if (talc_batch_create(ctx, in.p, c->offsets.data(), n, &b) != TALC_OK) { setFailed(); break; }
         // < 0: a real HIP / argument error stops the run; TALC_WARN_READ_ERRORS (> 0) is a complete batch in which some
         // reads kept their input sequence (status TALC_READ_ERROR -> a .log line), and the run goes on
         const int crc = talc_batch_correct(ctx, b);
         if (crc < 0) { setFailed(); talc_batch_destroy(b); break; }
         const uint64_t total = talc_batch_corrected_bytes(b);
-        std::vector<char> buf(std::max<uint64_t>(total, 1));
         std::vector<uint64_t> oo(n + 1);
-        if (talc_batch_fetch_corrected(ctx, b, buf.data(), total, oo.data(), c->status.data()) != TALC_OK) { setFailed(); talc_batch_destroy(b); break; }
-        for (uint32_t i = 0; i < n; ++i) c->out[i].assign(buf.data() + oo[i], oo[i + 1] - oo[i]);
+        if (!outb.reserve(std::max<uint64_t>(total, 1))) { setFailed(); talc_batch_destroy(b); break; }
+        if (talc_batch_fetch_corrected(ctx, b, outb.p, total, oo.data(), c->status.data()) != TALC_OK) { setFailed(); talc_batch_destroy(b); break; }
+        if (o.readStats) { c->stats.resize(5ull * n); if (talc_batch_fetch_read_stats(ctx, b, c->stats.data()) != TALC_OK) { setFailed(); talc_batch_destroy(b); break; } }
+        for (uint32_t i = 0; i < n; ++i) c->out[i].assign(outb.p + oo[i], oo[i + 1] - oo[i]);
         if (crc > 0) for (uint32_t i = 0; i < n; ++i) readErrors += c->status[i] == TALC_READ_ERROR ? 1 : 0;
         talc_batch_destroy(b);
       }

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "talc_table_next_counts_batch", "talc_table_lookup_host_batch", "talc_table_destroy",
     "talc_ctx_create", "talc_ctx_destroy", "talc_batch_create", "talc_batch_destroy",
     "talc_batch_coverage", "talc_batch_fetch_coverage", "talc_batch_num_kmers", "talc_batch_num_bases",
-    "talc_batch_correct", "talc_batch_corrected_bytes", "talc_batch_fetch_corrected",
+    "talc_batch_correct", "talc_batch_corrected_bytes", "talc_batch_fetch_corrected", "talc_batch_fetch_read_stats",
     "talc_batch_copy_corrected_device", "talc_correct_batch",
     "talc_ctx_get_timing", "talc_batch_trace_read", "talc_test_dp",
 ]
@@ -139,6 +139,7 @@ def lib():
         L.talc_batch_corrected_bytes.argtypes = [vp]
         L.talc_batch_fetch_corrected.argtypes = [vp, vp, vp, u64, vp, vp]
         L.talc_batch_copy_corrected_device.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.talc_batch_fetch_read_stats.argtypes = [vp, vp, vp]
         L.talc_correct_batch.argtypes = [vp, vp, vp, u32, vp, u64, vp, vp]
         L.talc_ctx_get_timing.argtypes = [vp, C.POINTER(Timing)]
         L.talc_batch_trace_read.restype = C.c_int64
@@ -390,6 +391,12 @@ class Batch:
         st = np.empty(self.n_reads, dtype=np.int32)
         _chk(lib().talc_batch_fetch_corrected(self.ctx._h, self._h, out.ctypes.data, total, oo.ctypes.data, st.ctypes.data))
         return out[:total], oo, st
+
+    def fetch_read_stats(self):
+        """int64[n, 5]: {row written, raw length, IN-region span, IN regions, corrected length} (Read.cpp:418-433)."""
+        st = np.zeros((self.n_reads, 5), dtype=np.int64)
+        _chk(lib().talc_batch_fetch_read_stats(self.ctx._h, self._h, st.ctypes.data))
+        return st
 
     @property
     def corrected_bytes(self):

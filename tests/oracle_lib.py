@@ -61,6 +61,8 @@ def lib():
                                     C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.orc_correct_batch.argtypes = [C.c_void_p, C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_uint32,
                                         C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_correct_batch_stats.argtypes = [C.c_void_p, C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_uint32,
+                                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_trace_read.restype = C.c_int64
         L.orc_trace_read.argtypes = [C.c_void_p, C.POINTER(OrcParams), C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
         L.orc_ub_counters.argtypes = [C.c_void_p]
@@ -174,6 +176,23 @@ class OracleTable:
                                          out.ctypes.data, cap, oo.ctypes.data, st.ctypes.data, nthreads)
             if rc == 0:
                 return out[: int(oo[n])].copy(), oo, st
+            cap = int(oo[n]) + 16
+
+    def correct_batch_stats(self, bases, offsets, nthreads=1):
+        """correct_batch plus the rows of Read::outputBasicReadStats: int64[n, 5]."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        cap = int(len(bases)) * 2 + 1024
+        while True:
+            out = np.empty(cap, dtype=np.uint8)
+            oo = np.empty(n + 1, dtype=np.uint64)
+            st = np.empty(n, dtype=np.int32)
+            rows = np.zeros((n, 5), dtype=np.int64)
+            rc = lib().orc_correct_batch_stats(self._h, C.byref(self.p), bases.ctypes.data, offsets.ctypes.data, n,
+                                               out.ctypes.data, cap, oo.ctypes.data, st.ctypes.data, nthreads, rows.ctypes.data)
+            if rc == 0:
+                return out[: int(oo[n])].copy(), oo, st, rows
             cap = int(oo[n]) + 16
 
     def trace(self, seq, steps=False):

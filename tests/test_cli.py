@@ -133,8 +133,9 @@ def test_cli_fails_loudly_without_gpu(cli, data, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["-j", "JUNC"], ["-rev"], ["--MIN_COUNT", "3", "--MAX_NB_BRANCHES", "5", "--batch-reads", "7"]],
-                         ids=["default", "junctions", "reverse", "params+small-batches"])
+@pytest.mark.parametrize("extra", [[], ["-j", "JUNC"], ["-rev"], ["--MIN_COUNT", "3", "--MAX_NB_BRANCHES", "5", "--batch-reads", "7"],
+                                   ["--read-stats", "--batch-reads", "7"]],
+                         ids=["default", "junctions", "reverse", "params+small-batches", "read-stats"])
 def test_cli_end_to_end_files_identical_to_reference_driver(cli, data, tmp_path, extra):
     extra = [str(data / "junc.dump") if x == "JUNC" else x for x in extra]
     reads = str(data / "reads.fq") if "-rev" in extra else str(data / "reads.fa")
@@ -149,5 +150,8 @@ def test_cli_end_to_end_files_identical_to_reference_driver(cli, data, tmp_path,
     assert fa[".log"] == fb[".log"]
     assert fa[".config.txt"].replace(b"gpu", b"ref") == fb[".config.txt"]
     assert fa[".stats_basics.txt"] == fb[".stats_basics.txt"]
+    if "--read-stats" in extra:      # the rows of Read::outputBasicReadStats (Read.cpp:418-433), one per read longer than K
+        rows = fa[".stats_basics.txt"].split(b"\n")[2:]
+        assert len(rows) >= 55 and all(len(r.split(b"\t")) == 5 for r in rows)
     lines = fa[".fa"].splitlines()
     assert len([l for l in lines if l.startswith(b">")]) == 60 and max(len(l) for l in lines if not l.startswith(b">")) == 70

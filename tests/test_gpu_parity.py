@@ -403,6 +403,26 @@ def test_batch_composition_and_order_do_not_matter(gpu_pair):
     assert np.array_equal(pst[np.argsort(perm)], st)
 
 
+def test_read_stats_rows_match_oracle(gpu_pair):
+    """The rows Read::outputBasicReadStats would append (Read.cpp:418-433; the reference has the call commented out,
+    main.cpp:305): raw length, span and number of the IN regions as the read's last step leaves them, corrected
+    length — for corrected reads, reads without a solid k-mer, reads without a structure and reads of K bases or fewer."""
+    base, offs0 = gpu_pair.reads(12000, 150)
+    r = PU.seqs_of(base, offs0)
+    reads = r + ["", r[0][:21], r[1][:22], "ACGT" * 200, "N" * 80,
+                 "".join(random.Random(5).choice("ACGT") for _ in range(900))]
+    bases, offs = pack(reads)
+    o_out, o_off, o_st, o_rows = gpu_pair.otab.correct_batch_stats(bases, offs, nthreads=8)
+    b = gpu_pair.ctx.batch(bases, offs)
+    b.correct()
+    g_out, g_off, g_st = b.fetch_corrected()
+    g_rows = b.fetch_read_stats()
+    b.close()
+    assert np.array_equal(np.asarray(o_st), g_st) and np.array_equal(o_out, g_out)
+    assert np.array_equal(o_rows, g_rows), np.nonzero((o_rows != g_rows).any(axis=1))[0][:10]
+    assert set(o_st.tolist()) >= {0, 1, 2} and (o_rows[:, 0] == 0).sum() >= 2 and (o_rows[:, 4] > 0).sum() > 120
+
+
 def test_trace_hook_matches_oracle(gpu_pair):
     bases, offs = gpu_pair.reads(9000, 3)
     for i in range(3):

@@ -317,3 +317,32 @@ def test_gardening_kats():
     assert kept == [1, 3, 5, 7, 6, 4, 2] + [1, 3, 5, 7, 6, 4, 2, 0]
     # all scores equal and the best distance among them: rank sum 0 exists, single survivor
     assert gard([5] * 9, [0.9, 0.1, 0.8, 0.2, 0.7, 0.3, 0.6, 0.4, 0.5]) == ([1], False)
+
+
+def test_basic_read_stats_row_follows_the_reference():
+    """Read::outputBasicReadStats (Read.cpp:418-433): span = sum of end - start + 1 over the IN regions as they stand,
+    their number, the raw length and length(m_correction) — which is empty unless correct2 ran; the call sits inside
+    `if (getLength() > K)` (main.cpp:262,305), so shorter reads get no row."""
+    import parity_util as PU
+    pair = PU.Pair(target_kmers=60_000, k=21, seed=5)
+    bases, offs = pair.reads(0, 30)
+    seqs = PU.seqs_of(bases, offs) + ["ACGTACGTACGTACGTACGTA", "A" * 300, "ACGT"]
+    rb = "".join(seqs).encode()
+    o = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    o[1:] = np.cumsum([len(x) for x in seqs])
+    out, oo, st, rows = pair.otab.correct_batch_stats(np.frombuffer(rb, dtype=np.uint8), o, nthreads=2)
+    out2, oo2, st2 = pair.otab.correct_batch(np.frombuffer(rb, dtype=np.uint8), o, nthreads=2)
+    assert np.array_equal(out, out2) and np.array_equal(st, st2)
+    for i, sq in enumerate(seqs):
+        if len(sq) <= 21:
+            assert rows[i].tolist() == [0, 0, 0, 0, 0]
+            continue
+        assert rows[i, 0] == 1 and rows[i, 1] == len(sq)
+        if st[i] == 0:
+            assert rows[i, 4] == int(oo[i + 1] - oo[i]) and rows[i, 3] >= 1 and rows[i, 2] >= rows[i, 3]
+            reg, thr, ok = pair.otab.structure(sq)
+            assert ok and rows[i, 3] == len(reg)          # correction moves region borders, never their number
+        else:
+            assert rows[i, 4] == 0
+        if st[i] == 2:
+            assert rows[i, 2] == 0 and rows[i, 3] == 0
