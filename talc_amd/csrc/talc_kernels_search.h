@@ -476,9 +476,11 @@ struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online 
 };
 
 enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
-       PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS, PF_N };
+       PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
+       PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
-                       "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps"}
+                       "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
+                       "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords"}
 
 struct Wv {
   // kernel constants
@@ -1660,6 +1662,8 @@ TALC_D uint32_t dpp_row_shr(uint32_t v, uint32_t old) {
 
 template <bool dirRight>
 TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
+  PROF_DECL; PROF_DECL2;
+  PROF_BEGIN2();
   const DevParams& P = X.P;
   const int l = lane_id();
   const bool edge = uni((int)edge_) != 0;
@@ -1692,6 +1696,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   auto flush = [&]() {
     const int n = done - flushed;
     if (n <= 0) return;
+    PROF_DECL; PROF_BEGIN();
     // distance terms |c - n| / sqrt(c) (Explorer.cpp:1247): c of step j is n of step j-1
     const uint32_t cn = (l < n) ? recN[l] : 1u;
     const uint32_t cprev = (l == 0) ? cFlush : ((l < n) ? recN[l - 1] : 1u);
@@ -1706,6 +1711,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     cFlush = (uint32_t)lane_get((int)cn, n - 1);
     flushed = done;
     LSYNC();
+    PROF_END(PF_FFFLUSH);
   };
 
   // lane j < 14 reads level j, lanes 14 / 15 the two halves of the key (the lanes above them repeat lane 14)
@@ -1713,8 +1719,10 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   const int lj = min(l, TALC_WALK_LEVELS - 1);                // shift amounts stay in range on the idle lanes
   uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
   uint32_t hh = (uint32_t)(table_hash(key) >> 32);
+  PROF_END2(PF_FFENTRY);
   while (done < maxSteps) {
     if (done - flushed > 64 - TALC_WALK_LEVELS) flush();
+    PROF_BEGIN();
     uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
     uint32_t e = wtab[slot * 16 + laneOff];
     bool found = true;
@@ -1725,7 +1733,12 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
       if (++slot == cap) slot = 0;
       e = wtab[slot * 16 + laneOff];
     }
+    PROF_END(PF_FFLOAD);
+#ifdef TALC_PROF
+    if (l == 0) g_prof[PF_NRECS] += 1;
+#endif
     if (!found) break;
+    PROF_BEGIN();
     const uint32_t top = e & 0xFFFFu, next = (e >> 16) & kWalkNextMask;
     // levels that are "exactly one successor with count >= MIN_COUNT", from level 0 up to the first that is not
     const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && top != kWalkTopNone && top >= MINC && next < MINC);
@@ -1789,6 +1802,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     cnt = (uint32_t)lane_get((int)top, last);
     done += nTake;
     LSYNC();
+    PROF_END(PF_FFREC);
     if (aimIdx >= 0) {
       // recordBridge (Explorer.cpp:1097-1101) for the Trail as it stands after this step
       flush();
@@ -1963,14 +1977,25 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
         // one candidate: its score is never compared, and its identity only with MIN_INNER (Explorer.cpp:973): the
         // least LCS that passes, T, is enough — lcs >= T  <=>  (double)lcs / maxLen >= MIN_INNER (monotone in lcs)
         int accept = 0;
+        bool needed = true;
         if (X.nFull == 1 && P.MIN_INNER > 0.0) {
           const double mxl = (double)max(X.refLen, fm.len);
           int T = (int)ceil(P.MIN_INNER * mxl);
           while (T > 1 && (double)(T - 1) / mxl >= P.MIN_INNER) --T;
           while ((double)T / mxl < P.MIN_INNER) ++T;
           accept = T;
+          // ... and only if its length passes: Explorer.cpp:973 and-s the two tests, and a lone candidate whose cut
+          // length fails the first one is rejected whatever its identity is (same arithmetic as the test below)
+          uint32_t cutLen1 = 0; bool ok1 = true;
+          if (fm.len >= 2 * K) cutLen1 = fm.len - 2 * K;
+          else if (fm.len > K) ok1 = ((uint32_t)fm.ranc + 2 * K - fm.len <= limit2);
+          else ok1 = false;
+          const uint32_t bestLen1 = ok1 ? cutLen1 : 0u;
+          const double diff1 = (double)X.weakLen - (double)bestLen1;
+          needed = ok1 && ((diff1 < X.weakLen * 0.05) || ((X.weakLen < 6) & (bestLen1 < 6)));
         }
-        edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs, X.nFull > 1, accept);
+        es = 0; lcs = 0;
+        if (uni((int)needed)) edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs, X.nFull > 1, accept);
         score = (double)es;
         idv = (double)lcs / (double)max(X.refLen, fm.len);
         // cutAnchors INNER (Trajectory.cpp:176-197)
