@@ -56,6 +56,7 @@ def parse(argv=None):
                     help="oracle table: flat hash (quick to build) or the reference's std::map (SURVEY §8d)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host pass")
+    ap.add_argument("--no-paralog", action="store_true", help="skip the branching-graph (paralog families) side measurement")
     return ap.parse_args(argv)
 
 
@@ -269,6 +270,8 @@ def main():
         h2h = host_to_host(T, table, params, dev, bases, offs, max(2, a.steps), log)
         if rank == 0:
             result["host_to_host"] = h2h
+    if world == 1 and not a.no_paralog and rank == 0:
+        result["paralog_workload"] = paralog_workload(T, dev, log)
     if rank == 0:
         if not a.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(a, w, synth, keys, counts, bases, offs, out, oo, st)
@@ -338,6 +341,40 @@ def host_to_host(T, table, params, dev, bases, offs, passes, log):
     return {"value": nb / dt, "unit": "bases/s", "ms_per_step": 1e3 * dt, "sub_batches": nsub, "contexts": len(ctxs),
             "what": "host buffers in -> corrected records back in host buffers (H2D + kernels + D2H, overlapped across "
                     "two contexts); table upload and FASTA parsing/writing not included"}
+
+
+def paralog_workload(T, dev, log):
+    """A side figure, never `value`: the same hot path on a transcriptome with paralog families (60 % of the transcripts
+    are 5 %-diverged copies of others, K = 25) — forks and bubbles in the graph, so most searches carry several Trails
+    and the time goes to scoreBridges / gardening / the generic expansion step (Explorer.cpp:546-612,689-865) instead
+    of the single-Trail fast path the headline workload lives on."""
+    from talc_amd.synth import Synth
+    S = Synth(target_kmers=2_000_000, k=25, seed=77, paralog_frac=0.6, paralog_div=0.05)
+    keys, counts = S.dump_arrays()
+    p = T.default_params(k=25)
+    tab = T.Table.from_arrays(keys, counts, p, device=dev)
+    tab.decolour_repeats()
+    tab.upload(dev)
+    ctx = T.Context(tab, p, dev)
+    n = 20_000
+    bases, offs = S.reads(0, n)
+    b = ctx.batch(bases, offs)
+    b.correct()                      # warm-up
+    t0 = time.perf_counter()
+    for _ in range(2):
+        b.correct()
+    dt = (time.perf_counter() - t0) / 2
+    tm = ctx.timing()
+    nb = b.n_bases
+    res = {"value": nb / dt, "unit": "bases/s", "ms_per_step": 1e3 * dt, "reads": n, "bases": nb, "k": 25,
+           "table_kmers": len(tab), "search_ms": tm.search_ms, "retry_ms": tm.retry_ms, "n_retried": tm.n_retried,
+           "n_failed": tm.n_failed, "trail_steps": tm.n_trail_steps, "dp_cells": tm.n_dp_cells,
+           "what": "20 k reads on a 2 M-base transcriptome with 60 % paralogs at 5 % divergence, K = 25 (branching graph)"}
+    log("paralog workload: %.1f ms per pass of %d reads (%.3g bases/s)" % (1e3 * dt, n, nb / dt))
+    b.close()
+    ctx.close()
+    tab.close()
+    return res
 
 
 def cpu_baseline(a, w, synth, keys, counts, bases, offs, g_out, g_off, g_st):

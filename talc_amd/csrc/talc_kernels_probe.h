@@ -102,6 +102,29 @@ __global__ void k_encode(const uint8_t* __restrict__ raw, uint8_t* __restrict__ 
 //  #{count > MIN_COUNT} (Read.cpp:190) is reduced per block and added to the read's counter.
 #define COV_TILE 2048
 #define COV_THREADS 256
+#ifndef TALC_COV_QUEUE
+#define TALC_COV_QUEUE 1   /* 0: probe inside phase A (experiment) */
+#endif
+
+// the table part of one lookup: (count, colour | out-degrees) of a k-mer that passed the filter
+TALC_D void cov_probe(const TableView& T, uint64_t kmer, uint32_t min_count, uint32_t& c, uint32_t& j) {
+  const uint32_t K = T.k;
+  c = 0; j = 0;
+  dev_get_count(T, kmer, c, j);
+  if (c != 0) {
+    // a k-mer of the table: its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this
+    // MIN_COUNT) ride in the colour word's upper half — the anchor search asks for them position by position
+    // (Explorer.cpp:449,515) and would otherwise probe, one dependent access at a time
+    const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
+    BucketRegs br;
+    uint32_t dR = 0, dL = 0;
+    if (probe_bucket(T.right, T.capacity, kmer & m1, br))
+      dR = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
+    if (probe_bucket(T.left, T.capacity, kmer >> 2, br))
+      dL = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
+    j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
+  }
+}
 
 __global__ void __launch_bounds__(COV_THREADS)
 k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
@@ -186,6 +209,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   const uint64_t nBlocks = T.filterWords >> 3;
   const uint64_t TALC_AS1* filter = (const uint64_t TALC_AS1*)T.filter;
   v2u32 TALC_AS1* out = (v2u32 TALC_AS1*)(cov + koff[r] + p0);
+  int local_in = 0;
   // ---- phase A
   for (uint32_t pb = 0; pb < cnt; pb += COV_THREADS) {
     const uint32_t p = pb + threadIdx.x;
@@ -206,6 +230,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
 #endif
         maybe = (filter[idx] & m) == m;
       }
+#if TALC_COV_QUEUE
       if (!maybe) out[p] = v2u32{0u, 0u};
     }
     // queue the survivors: one LDS atomic per wave
@@ -221,28 +246,21 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   __syncthreads();
   // ---- phase B
   const uint32_t qn = s_qn;
-  const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
-  int local_in = 0;
   for (uint32_t qi = threadIdx.x; qi < qn; qi += COV_THREADS) {
     const uint32_t p = s_queue[qi];
-    const uint64_t kmer = window(p) >> kshift;
-    uint32_t c = 0, j = 0;
-    dev_get_count(T, kmer, c, j);
-    if (c != 0) {
-      // a k-mer of the table: its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this
-      // MIN_COUNT) ride in the colour word's upper half — the anchor search asks for them position by position
-      // (Explorer.cpp:449,515) and would otherwise probe, one dependent access at a time
-      BucketRegs br;
-      uint32_t dR = 0, dL = 0;
-      if (probe_bucket(T.right, T.capacity, kmer & m1, br))
-        dR = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
-      if (probe_bucket(T.left, T.capacity, kmer >> 2, br))
-        dL = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
-      j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
-    }
+    uint32_t c, j;
+    cov_probe(T, window(p) >> kshift, min_count, c, j);
     out[p] = v2u32{c, j};
     local_in += (c > min_count) ? 1 : 0;
   }
+#else
+      uint32_t c = 0, j = 0;
+      if (maybe) cov_probe(T, window(p) >> kshift, min_count, c, j);
+      out[p] = v2u32{c, j};
+      local_in += (c > min_count) ? 1 : 0;
+    }
+  }
+#endif
   // block reduction of local_in
   for (int off = 32; off > 0; off >>= 1) local_in += __shfl_down(local_in, off, 64);
   if ((threadIdx.x & 63) == 0 && local_in) atomicAdd(&s_nin, local_in);
