@@ -621,12 +621,23 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
     } else {   // no bound from the edit distance: narrowest wavefront first (-1 = it needs more levels than that width holds)
       if (lo <= 31 && la <= 220) d = wave_wfa_global<1, false>(stage, qpad, la, lb, ncells, acceptA);
       if (d == -1 && lo <= 63 && la <= 440) d = wave_wfa_global<2, false>(stage, qpad, la, lb, ncells, acceptA);
-      if (d == -1 && lo <= 127) d = wave_wfa_global<4, false>(stage, qpad, la, lb, ncells, acceptA);
+      // (beyond that the bit-parallel LCS below: its cost is per row, not per level x diagonal)
     }
     if (d >= 0) { lcsLen = (la + lb - d) >> 1; haveLcs = true; }
     else if (d == -2) { lcsLen = acceptLcs; haveLcs = true; }   // proven: LCS >= acceptLcs
     X.cells += ncells;
     WSYNC();
+  }
+  if (haveEdit && haveLcs) return;
+  if (!haveLcs) {   // long or dissimilar sequences: the bit-vector LCS (exact; up to 4096 columns)
+    unsigned long long ncells = 0;
+    const int z = wave_lcs_bitpar(a, la, b, lb, ncells);
+    if (z >= 0) { lcsLen = z; haveLcs = true; X.cells += ncells; }
+  }
+  if (!haveEdit) {  // ... and the bit-vector edit distance
+    unsigned long long ncells = 0;
+    const int ed = wave_edit_bitpar(a, la, b, lb, ncells);
+    if (ed >= 0) { editScore = -ed; haveEdit = true; X.cells += ncells; }
   }
   if (haveEdit && haveLcs) return;
   if (!haveEdit && !haveLcs && la <= 64 * NW2_REG_NB) {

@@ -868,6 +868,149 @@ TALC_D int wave_wfa_global(const uint8_t TALC_AS3* stage, int qpad, int qlen, in
   return result;
 }
 
+TALC_D unsigned long long load_u64_unaligned_fwd(gcu8 p) {
+  typedef unsigned long long __attribute__((aligned(1))) u64u;
+  return *(const u64u TALC_AS1*)p;
+}
+
+// ------------------------------------------------------------------ bit-parallel LCS (long sequences)
+// LCS length of two sequences by the bit-vector recurrence of Crochemore et al. / Hyyro (2004): with the columns of
+// the DP matrix as the bits of V (1 = the row's LCS value does not grow at that column),
+//     V' = (V + (V & M[b])) | (V & ~M[b])        M[b] = columns whose base equals the row's base b
+// row by row, and LCS = number of 0 bits in the final V.  The columns span the wave: lane l holds bits [64 l, 64 l + 63],
+// so up to 4096 columns; the one cross-lane dependency is the carry of the addition, resolved per row with two ballots
+// and scalar arithmetic: a lane generates a carry (g) or would pass one on (p, its sum is all ones) — never both — and
+// the carries into the lanes are ((G << 1) + P) ^ P | (G << 1)  (verified exhaustively; tests/test_pure_vs_oracle.py).
+// About 40 instructions per ROW whatever the number of columns, against cells / 64 for the lane-skewed DP and
+// levels x diagonals for the wavefront forms: this is the routine for sequences beyond a few hundred bases (K = 31
+// gaps, config 5).  Equal codes match (N with N, like Score<int,Simple>).  Returns -1 if neither sequence
+// fits 4096 columns.
+TALC_D int wave_lcs_bitpar(const uint8_t* __restrict__ a_, int la, const uint8_t* __restrict__ b_, int lb, unsigned long long& cells) {
+  la = uni(la); lb = uni(lb);
+  if (la == 0 || lb == 0) return 0;
+  // columns = the longer sequence if it fits (the cost is per row), else the shorter one
+  const uint8_t* colp = uni_ptr(a_); int m = la; const uint8_t* rowp = uni_ptr(b_); int n = lb;
+  if ((la < lb && lb <= 4096) || la > 4096) { colp = uni_ptr(b_); m = lb; rowp = uni_ptr(a_); n = la; }
+  if (m > 4096) return -1;
+  cells += (unsigned long long)la * (unsigned long long)lb;
+  gcu8 cs = (gcu8)colp; gcu8 rs = (gcu8)rowp;
+  const int l = lane_id_here();
+  // match masks of this lane's 64 columns, one per code
+  unsigned long long pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0, pm4 = 0;
+  {
+    const int c0 = 64 * l;
+    for (int w = 0; w < 8; ++w) {
+      const int base = c0 + 8 * w;
+      if (base >= m) break;
+      unsigned long long bytes = 0;
+      if (base + 8 <= m) bytes = load_u64_unaligned_fwd(cs + base);
+      else for (int i = 0; base + i < m; ++i) bytes |= (unsigned long long)cs[base + i] << (8 * i);
+      const int nb = min(8, m - base);
+      for (int i = 0; i < nb; ++i) {
+        const unsigned c = (unsigned)(bytes >> (8 * i)) & 0xFFu;
+        const unsigned long long bit = 1ull << (8 * w + i);
+        pm0 |= (c == 0u) ? bit : 0ull; pm1 |= (c == 1u) ? bit : 0ull; pm2 |= (c == 2u) ? bit : 0ull;
+        pm3 |= (c == 3u) ? bit : 0ull; pm4 |= (c == 4u) ? bit : 0ull;
+      }
+    }
+  }
+  const unsigned long long laneBit = 1ull << l;
+  unsigned long long V = ~0ull;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int jn = min(64, n - j0);
+    const int bvec = (l < jn) ? (int)rs[j0 + l] : 0;
+    for (int jj = 0; jj < jn; ++jj) {
+      const int b = lane_get(bvec, jj);     // the row's base, wave-uniform
+      const unsigned long long M = (b == 0) ? pm0 : (b == 1) ? pm1 : (b == 2) ? pm2 : (b == 3) ? pm3 : pm4;
+      const unsigned long long U = V & M;
+      unsigned long long S = V + U;
+      const unsigned long long G = ballot64(S < V), P = ballot64(S == ~0ull);
+      const unsigned long long Y = G << 1;
+      const unsigned long long C = ((Y + P) ^ P) | Y;
+      S += (C & laneBit) ? 1ull : 0ull;
+      V = S | (V & ~M);
+    }
+  }
+  // zeros among the m column bits
+  const int mine = max(0, min(64, m - 64 * l));
+  const unsigned long long colMask = (mine >= 64) ? ~0ull : ((1ull << mine) - 1);
+  int z = __popcll(~V & colMask);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+  return z;
+}
+
+// ------------------------------------------------------------------ bit-parallel edit distance (long sequences)
+// Global edit distance (= minus the globalAlignment score with match 0, mismatch -1, gap -1; Trail.cpp:422,
+// Trajectory.cpp:413) by Myers' bit-vector algorithm in Hyyro's formulation: the pattern's positions are the bits (lane l
+// holds bits [64 l, 64 l + 63], up to 4096), the other sequence is consumed base by base; Pv / Mv are the vertical
+// +1 / -1 deltas of the current column, the horizontal delta of row 0 is +1 (the matrix border of a global alignment).
+// The addition's carry crosses the lanes as in wave_lcs_bitpar, the two shifts by one take the top bit of the lane
+// below.  About 60 instructions per base of the consumed sequence whatever the pattern's length.  -1: neither fits.
+TALC_D int wave_edit_bitpar(const uint8_t* __restrict__ a_, int la, const uint8_t* __restrict__ b_, int lb, unsigned long long& cells) {
+  la = uni(la); lb = uni(lb);
+  if (la == 0 || lb == 0) return la + lb;
+  const uint8_t* patp = uni_ptr(a_); int m = la; const uint8_t* txtp = uni_ptr(b_); int n = lb;
+  if ((la < lb && lb <= 4096) || la > 4096) { patp = uni_ptr(b_); m = lb; txtp = uni_ptr(a_); n = la; }
+  if (m > 4096) return -1;
+  cells += (unsigned long long)la * (unsigned long long)lb;
+  gcu8 ps = (gcu8)patp; gcu8 ts = (gcu8)txtp;
+  const int l = lane_id_here();
+  unsigned long long pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0, pm4 = 0;
+  {
+    const int c0 = 64 * l;
+    for (int w = 0; w < 8; ++w) {
+      const int base = c0 + 8 * w;
+      if (base >= m) break;
+      unsigned long long bytes = 0;
+      if (base + 8 <= m) bytes = load_u64_unaligned_fwd(ps + base);
+      else for (int i = 0; base + i < m; ++i) bytes |= (unsigned long long)ps[base + i] << (8 * i);
+      const int nb = min(8, m - base);
+      for (int i = 0; i < nb; ++i) {
+        const unsigned c = (unsigned)(bytes >> (8 * i)) & 0xFFu;
+        const unsigned long long bit = 1ull << (8 * w + i);
+        pm0 |= (c == 0u) ? bit : 0ull; pm1 |= (c == 1u) ? bit : 0ull; pm2 |= (c == 2u) ? bit : 0ull;
+        pm3 |= (c == 3u) ? bit : 0ull; pm4 |= (c == 4u) ? bit : 0ull;
+      }
+    }
+  }
+  const unsigned long long laneBit = 1ull << l;
+  const int topLane = (m - 1) >> 6, topBit = (m - 1) & 63;
+  unsigned long long Pv = ~0ull, Mv = 0ull;
+  int score = m;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int jn = min(64, n - j0);
+    const int bvec = (l < jn) ? (int)ts[j0 + l] : 0;
+    for (int jj = 0; jj < jn; ++jj) {
+      const int b = lane_get(bvec, jj);
+      const unsigned long long Eq = (b == 0) ? pm0 : (b == 1) ? pm1 : (b == 2) ? pm2 : (b == 3) ? pm3 : pm4;
+      const unsigned long long Xv = Eq | Mv;
+      const unsigned long long Xa = Eq & Pv;
+      unsigned long long S = Xa + Pv;
+      const unsigned long long G = ballot64(S < Pv), P = ballot64(S == ~0ull);
+      const unsigned long long Y = G << 1;
+      const unsigned long long C = ((Y + P) ^ P) | Y;
+      S += (C & laneBit) ? 1ull : 0ull;
+      const unsigned long long Xh = (S ^ Pv) | Eq;
+      unsigned long long Ph = Mv | ~(Xh | Pv);
+      unsigned long long Mh = Pv & Xh;
+      // the delta of the last row: bit m-1
+      const unsigned long long up = ballot64(l == topLane && ((Ph >> topBit) & 1ull)), dn = ballot64(l == topLane && ((Mh >> topBit) & 1ull));
+      score += (up != 0ull) ? 1 : 0;
+      score -= (dn != 0ull) ? 1 : 0;
+      // shift by one across the lanes: lane 0 takes the border's +1 (Ph) / 0 (Mh)
+      int pTop = (int)(Ph >> 63), mTop = (int)(Mh >> 63);
+      pTop = lane_shr1(pTop); mTop = lane_shr1(mTop);
+      if (l == 0) { pTop = 1; mTop = 0; }
+      Ph = (Ph << 1) | (unsigned long long)(unsigned)pTop;
+      Mh = (Mh << 1) | (unsigned long long)(unsigned)mTop;
+      Pv = Mh | ~(Xv | Ph);
+      Mv = Ph & Xv;
+    }
+  }
+  return score;
+}
+
 // ------------------------------------------------------------------ k-mer window search
 // Occurrences of pat[0..K) in seq[0..len): returns the first (wantLast=false) or the last
 // (wantLast=true) start index, or -1.  Replaces Finder/Pattern<Horspool> (Trail.cpp:295-298).

@@ -117,8 +117,8 @@ def test_device_edit_distance_and_lcs_match_oracle(gpu_pair):
     rnd = random.Random(13)
     L = O.lib()
     ctx = gpu_pair.ctx
-    for it in range(90):
-        n = rnd.choice([0, 1, 5, 40, 63, 64, 65, 130, 219, 221, 400, 441, 700, 1279, 1800])
+    for it in range(110):
+        n = rnd.choice([0, 1, 5, 40, 63, 64, 65, 130, 219, 221, 400, 441, 700, 1279, 1800, 2500, 4095, 4097, 4500])
         a = [rnd.choice("ACGTN" if rnd.random() < 0.1 else "ACGT") for _ in range(n)]
         kind = rnd.random()
         if kind < 0.7:
@@ -136,7 +136,7 @@ def test_device_edit_distance_and_lcs_match_oracle(gpu_pair):
             if rnd.random() < 0.3:
                 b = b[: rnd.randrange(len(b) + 1)]
         else:
-            b = [rnd.choice("ACGT") for _ in range(rnd.choice([0, 1, 7, 50, 64, 200, 900]))]
+            b = [rnd.choice("ACGT") for _ in range(rnd.choice([0, 1, 7, 50, 64, 200, 900, 4200]))]
         a, b = "".join(a), "".join(b)
         if rnd.random() < 0.5:
             a, b = b, a
