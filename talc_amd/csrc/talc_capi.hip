@@ -578,7 +578,7 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&c->d_counters, 32 * sizeof(uint64_t)));
+  HIPCHK(hipMalloc((void**)&c->d_counters, 64 * sizeof(uint64_t)));
   *out = c;
   return TALC_OK;
 }

@@ -468,7 +468,9 @@ struct TrailRec { uint64_t kmer, nmask; double dist; uint32_t cnt; int32_t score
 __shared__ TrailRec g_hot[2 * HOT];                 // metadata of the first HOT slots of both Trail sets
 __shared__ uint64_t g_aimK[AIMS_LDS], g_aimN[AIMS_LDS];
 __shared__ uint32_t g_aimPos[AIMS_LDS];             // first AIMS_LDS target anchors
-__shared__ unsigned long long g_bloom[64];          // 4096-bit k-mer Bloom filter of the current search
+#define BLOOM_WORDS 128
+__shared__ unsigned long long g_bloom[BLOOM_WORDS];  // 8192-bit k-mer Bloom filter of the current search (a K = 31 gap is
+                                                     // ~600 k-mers: at 4096 bits one step in twelve was a false alarm)
 __shared__ __attribute__((aligned(16))) int g_dp[3 * LDS_DP_CAP];                // x-drop stage / short DP arrays
 
 struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online (findBestBORDER is a fold)
@@ -477,10 +479,11 @@ struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online 
 
 enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
        PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
-       PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_N };
+       PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
                        "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
-                       "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords"}
+                       "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords", "#reads<0.25ms", "#reads<1ms", "#reads<4ms", \
+                       "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)"}
 
 struct Wv {
   // kernel constants
@@ -738,8 +741,9 @@ TALC_D uint64_t bloom_hash(uint64_t kmer, uint64_t nmask) {
   const uint64_t key = X.dirRight ? (kmer & ((1ULL << (2 * (K - 1))) - 1)) : (kmer >> 2);
   return table_hash(key) ^ (nmask * 0x9E3779B97F4A7C15ULL);
 }
-TALC_D int bloom_word(uint64_t h) { return (int)(h >> 58); }
-TALC_D unsigned long long bloom_mask(uint64_t h) { return (1ull << ((h >> 52) & 63)) | (1ull << ((h >> 46) & 63)); }
+TALC_D int bloom_word(uint64_t h) { return (int)(h >> 57); }
+TALC_D unsigned long long bloom_mask(uint64_t h) { return (1ull << ((h >> 51) & 63)) | (1ull << ((h >> 45) & 63)); }
+static_assert(BLOOM_WORDS == 128, "bloom_word takes 7 hash bits");
 TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
   const uint64_t h = bloom_hash(kmer, nmask);
   const int w = bloom_word(h);
@@ -1556,8 +1560,8 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
     if (edge) maxSteps = min(maxSteps, (int)(CHECK - (sc0 % CHECK)));   // up to and including the next scoring step
   }
   gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
-  const unsigned long long bw0 = g_bloom[l];
-  int bwLo = (int)(uint32_t)bw0, bwHi = (int)(uint32_t)(bw0 >> 32);
+  const unsigned long long bw0 = g_bloom[l], bw1 = g_bloom[l + 64];   // words l and l + 64 of the filter in this lane
+  int bwLo = (int)(uint32_t)bw0, bwHi = (int)(uint32_t)(bw0 >> 32), bxLo = (int)(uint32_t)bw1, bxHi = (int)(uint32_t)(bw1 >> 32);
   int recN = 0, recB = 0;
   uint32_t cFlush = cnt;   // count of the tip before the first unflushed step
   double dist = r0.dist;
@@ -1625,12 +1629,15 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
     // k-mer walked so far (init_first_trail), so "absent" means neither an aim nor a cycle; a possible hit of either
     // kind is left to the generic step, which redoes this step from the unchanged state
     const int bwi = bloom_word(h2);
+    const int bwl = bwi & 63;
+    const bool upper = (bwi & 64) != 0;
     const unsigned long long bm = bloom_mask(h2);
-    const unsigned long long bv = ((unsigned long long)(uint32_t)lane_get(bwHi, bwi) << 32) | (uint32_t)lane_get(bwLo, bwi);
+    const unsigned long long bv = upper ? (((unsigned long long)(uint32_t)lane_get(bxHi, bwl) << 32) | (uint32_t)lane_get(bxLo, bwl))
+                                        : (((unsigned long long)(uint32_t)lane_get(bwHi, bwl) << 32) | (uint32_t)lane_get(bwLo, bwl));
     if ((bv & bm) == bm) break;
     // ---- commit the step
-    bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwi);
-    bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwi);
+    if (upper) { bxLo = lane_set(bxLo, (int)(uint32_t)(bv | bm), bwl); bxHi = lane_set(bxHi, (int)(uint32_t)((bv | bm) >> 32), bwl); }
+    else { bwLo = lane_set(bwLo, (int)(uint32_t)(bv | bm), bwl); bwHi = lane_set(bwHi, (int)(uint32_t)((bv | bm) >> 32), bwl); }
     const int rs = done - flushed;
     recN = lane_set(recN, (int)nc, rs);
     recB = lane_set(recB, which, rs);
@@ -1642,6 +1649,7 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
 
   flush();
   g_bloom[l] = ((unsigned long long)(uint32_t)bwHi << 32) | (uint32_t)bwLo;
+  g_bloom[l + 64] = ((unsigned long long)(uint32_t)bxHi << 32) | (uint32_t)bxLo;
   stepCounter_ = sc0 + (uint32_t)done;
 #ifdef TALC_PROF
   if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (unsigned long long)done; }
@@ -1783,8 +1791,8 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     dup |= dpp_row_shr<13>(hv, ~hv) == hv;
     static_assert(TALC_WALK_LEVELS == 14, "the lane roles above are written for 14 levels in a 16-lane row");
     // aim / cycle query against the search's filter (init_first_trail entered the aims)
-    const int bwi = (int)(hv >> 26);
-    const unsigned long long bm = (1ull << ((hv >> 20) & 63u)) | (1ull << ((hv >> 14) & 63u));
+    const int bwi = (int)(hv >> 25);     // bloom_word / bloom_mask on the upper half of the hash
+    const unsigned long long bm = (1ull << ((hv >> 19) & 63u)) | (1ull << ((hv >> 13) & 63u));
     const unsigned long long bv = g_bloom[bwi];
     const unsigned long long hitMask = ballot64(((bv & bm) == bm) || dup) | (1ull << TALC_WALK_LEVELS);
     const int hitLevel = __builtin_ctzll(hitMask);
@@ -1871,7 +1879,7 @@ TALC_D void init_first_trail(const AnchorRec& a, bool withAims) {
   pool_reset();
   const uint32_t b0 = (uint32_t)pool_alloc();
   wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
-  g_bloom[lane_id()] = 0ull;
+  g_bloom[lane_id()] = 0ull; g_bloom[lane_id() + 64] = 0ull;
   LSYNC();
   if (withAims) {
     const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
@@ -2186,6 +2194,8 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
 #ifdef TALC_PROF
   if (l == 0) for (int i = 0; i < PF_N; ++i) g_prof[i] = 0;
   const unsigned long long _pf_k0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long _pf_r0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
+  unsigned long long _pf_rd0 = 0;
 #endif
 
   while (true) {
@@ -2194,6 +2204,15 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     WSYNC();
     const uint32_t qi = s_next;
     if (qi >= n_work) break;
+#ifdef TALC_PROF
+    if (l == 0 && _pf_rd0) {   // duration of the previous read of this wave (100 MHz ticks)
+      const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - _pf_rd0;
+      const int bk = dt < 25000ull ? 0 : dt < 100000ull ? 1 : dt < 400000ull ? 2 : dt < 1600000ull ? 3 : dt < 6400000ull ? 4 : 5;
+      g_prof[PF_RD0 + bk] += 1;
+      if (dt > g_prof[PF_RDMAX]) g_prof[PF_RDMAX] = dt;
+    }
+    _pf_rd0 = __builtin_amdgcn_s_memrealtime();
+#endif
     PROF_BEGIN2();
     const uint32_t r = order[qi];
     const uint64_t rb = offsets[r];
@@ -2348,7 +2367,17 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     if (totCells) atomicAdd((unsigned long long*)&counters[1], totCells);
 #ifdef TALC_PROF
     g_prof[PF_TOTAL] = __builtin_amdgcn_s_memtime() - _pf_k0;
-    for (int i = 0; i < PF_N; ++i) atomicAdd((unsigned long long*)&counters[2 + i], g_prof[i]);
+    {   // wave utilisation of the launch: sum of the waves' lifetimes against (last end - first start) x waves
+      const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+      atomicAdd((unsigned long long*)&counters[61], r1 - _pf_r0);   // (counters[2 .. 2 + PF_N) are the categories)
+      atomicMin((unsigned long long*)&counters[62], _pf_r0);
+      atomicMax((unsigned long long*)&counters[63], r1);
+      static_assert(2 + PF_N <= 61, "the profile categories run into the utilisation counters");
+    }
+    for (int i = 0; i < PF_N; ++i) {
+      if (i == PF_RDMAX) atomicMax((unsigned long long*)&counters[2 + i], g_prof[i]);
+      else atomicAdd((unsigned long long*)&counters[2 + i], g_prof[i]);
+    }
 #endif
   }
 }

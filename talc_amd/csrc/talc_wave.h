@@ -551,14 +551,19 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
       qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
       any |= act[s];
     }
+    // sixteen bases per round trip to the LDS (all four reads are issued before the first is used): the sentinels
+    // behind both segments end every run, and the stage leaves 16 bytes of slack behind each segment
     while (ballot64(any) != 0ull) {
       any = false;
 #pragma unroll
       for (int s = 0; s < NR; ++s) {
         if (act[s]) {
-          const unsigned long long w = lds_load_u64(stage + qa[s]) ^ lds_load_u64(stage + da[s]);
-          if (w == 0ull) { qa[s] += 8; da[s] += 8; a[s] += 16; any = true; }
-          else { a[s] += 2 * (__builtin_ctzll(w) >> 3); act[s] = false; }
+          const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
+          const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
+          const unsigned long long w0 = q0 ^ d0, w1 = q1 ^ d1;
+          if (w0 != 0ull) { a[s] += 2 * (__builtin_ctzll(w0) >> 3); act[s] = false; }
+          else if (w1 != 0ull) { a[s] += 16 + 2 * (__builtin_ctzll(w1) >> 3); act[s] = false; }
+          else { qa[s] += 16; da[s] += 16; a[s] += 32; any = true; }
         }
       }
     }
@@ -684,14 +689,19 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
       qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
       any |= act[s];
     }
+    // sixteen bases per round trip to the LDS (all four reads are issued before the first is used): the sentinels
+    // behind both segments end every run, and the stage leaves 16 bytes of slack behind each segment
     while (ballot64(any) != 0ull) {
       any = false;
 #pragma unroll
       for (int s = 0; s < NR; ++s) {
         if (act[s]) {
-          const unsigned long long w = lds_load_u64(stage + qa[s]) ^ lds_load_u64(stage + da[s]);
-          if (w == 0ull) { qa[s] += 8; da[s] += 8; a[s] += 16; any = true; }
-          else { a[s] += 2 * (__builtin_ctzll(w) >> 3); act[s] = false; }
+          const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
+          const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
+          const unsigned long long w0 = q0 ^ d0, w1 = q1 ^ d1;
+          if (w0 != 0ull) { a[s] += 2 * (__builtin_ctzll(w0) >> 3); act[s] = false; }
+          else if (w1 != 0ull) { a[s] += 16 + 2 * (__builtin_ctzll(w1) >> 3); act[s] = false; }
+          else { qa[s] += 16; da[s] += 16; a[s] += 32; any = true; }
         }
       }
     }
@@ -799,14 +809,19 @@ TALC_D int wave_wfa_global(const uint8_t TALC_AS3* stage, int qpad, int qlen, in
       qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
       any |= act[s];
     }
+    // sixteen bases per round trip to the LDS (all four reads are issued before the first is used): the sentinels
+    // behind both segments end every run, and the stage leaves 16 bytes of slack behind each segment
     while (ballot64(any) != 0ull) {
       any = false;
 #pragma unroll
       for (int s = 0; s < NR; ++s) {
         if (act[s]) {
-          const unsigned long long w = lds_load_u64(stage + qa[s]) ^ lds_load_u64(stage + da[s]);
-          if (w == 0ull) { qa[s] += 8; da[s] += 8; a[s] += 16; any = true; }
-          else { a[s] += 2 * (__builtin_ctzll(w) >> 3); act[s] = false; }
+          const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
+          const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
+          const unsigned long long w0 = q0 ^ d0, w1 = q1 ^ d1;
+          if (w0 != 0ull) { a[s] += 2 * (__builtin_ctzll(w0) >> 3); act[s] = false; }
+          else if (w1 != 0ull) { a[s] += 16 + 2 * (__builtin_ctzll(w1) >> 3); act[s] = false; }
+          else { qa[s] += 16; da[s] += 16; a[s] += 32; any = true; }
         }
       }
     }
