@@ -91,6 +91,7 @@ struct talc_ctx {
   talc_timing timing;
   Stage stage;          // default scratch
   uint32_t* d_queue = nullptr;   // work-queue counters
+  uint32_t* d_hist = nullptr;    // 1024 buckets of the work-queue ordering
   uint64_t* d_counters = nullptr;  // [0]=trail steps [1]=dp cells
   // device buffers of finished batches, kept for the next batch of this context (a streaming run creates and destroys
   // a batch per chunk of reads: ~20 hipMalloc / hipFree pairs each time otherwise)
@@ -578,6 +579,7 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&c->d_hist, 1024 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&c->d_counters, 64 * sizeof(uint64_t)));
   *out = c;
   return TALC_OK;
@@ -590,6 +592,7 @@ void talc_ctx_destroy(talc_ctx* c) {
   for (auto& e : c->pool) hipFree(e.second);
   for (auto& e : c->live) hipFree(e.first);   // (batches that outlived their context: their memory goes with it)
   if (c->d_queue) hipFree(c->d_queue);
+  if (c->d_hist) hipFree(c->d_hist);
   if (c->d_counters) hipFree(c->d_counters);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   if (c->stream) hipStreamDestroy(c->stream);

@@ -43,7 +43,7 @@ struct ReadState {
   uint32_t outLen;      // corrected length in codes (growth of the read's out slot)
   uint32_t overflow;    // OVF_* bits: scratch exhausted, read left unchanged
   uint32_t inSpan;      // sum over the IN regions of (end - start + 1), as they stand (Read.cpp:423: the stats row)
-  uint32_t pad_;
+  uint32_t costEst;     // k_structure's estimate of the search's work (orders the work queue: heaviest reads first)
 };
 
 __host__ __device__ inline uint64_t out_capacity_for(uint64_t L) { return 4 * L + 1024; }
@@ -255,7 +255,7 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   const uint8_t* read = codes + offsets[r];
   const uint32_t L = (uint32_t)(offsets[r + 1] - offsets[r]);
   ReadState st;
-  st.status = TALC_READ_CORRECTED; st.nRegions = 0; st.lambda = (double)MINC; st.outLen = 0; st.overflow = 0; st.inSpan = 0; st.pad_ = 0;
+  st.status = TALC_READ_CORRECTED; st.nRegions = 0; st.lambda = (double)MINC; st.outLen = 0; st.overflow = 0; st.inSpan = 0; st.costEst = 0;
   if (!(L > K)) { st.status = TALC_READ_SKIPPED_SHORT; if (l == 0) state[r] = st; return; }      // main.cpp:262
   if (!(n_in[r] > 0)) { st.status = TALC_READ_NO_SOLID_KMER; if (l == 0) state[r] = st; return; }  // Read.cpp:194
   const uint32_t n = L - K + 1;
@@ -431,6 +431,30 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     st.inSpan = (uint32_t)wave_sum_u64(part);
   }
   if (!checok) st.status = TALC_READ_NO_STRUCTURE;   // main.cpp:290
+  if (checok && Rfinal > 0) {
+    // What the path search will cost, roughly: an edge (head / tail of at most MAX_BORDER_LEN bases) is searched from up
+    // to five anchors, each for 1.2 x its length steps with a seed extension every CHECK_INTERVAL steps whose x grows
+    // with the path — quadratic in the edge's length, and the reason why a 1.2 kb read with a 480-base head takes ten
+    // times as long as a 3 kb read without one; an inner gap is walked once and evaluated once.  Only the order of the
+    // work queue depends on this number (measured: with the queue ordered by read length alone the waves were busy 63 %
+    // of the launch, waiting for a few late heavy reads).
+    // (in wave-cycles, from the category profile of config 2: a step of the walk ~ 460, a wavefront level ~ 1500,
+    //  a level per ~ 11 bases of path at 12 % error: an inner gap of g bases ~ 870 g + 20 000, an edge of h bases
+    //  ~ 5 anchors x (550 h + 27 h^2))
+    unsigned long long part = 0;
+    for (uint32_t i = l; i + 1 < Rfinal; i += 64) {
+      const unsigned long long g = (regS[i + 1] > regE[i] + K) ? (unsigned long long)(regS[i + 1] - (regE[i] + K)) : 0ull;
+      part += 870ull * g + 20000ull;
+    }
+    unsigned long long cost = wave_sum_u64(part);
+    const unsigned long long head = regS[0], eLast = regE[Rfinal - 1];
+    const unsigned long long tail = (eLast + 1 < n) ? (unsigned long long)L - (eLast + K) : 0ull;
+    if (head > 0 && head <= P.MAX_BORDER_LEN) cost += 2800ull * head + 135ull * head * head;
+    if (tail > 0 && tail <= P.MAX_BORDER_LEN) cost += 2800ull * tail + 135ull * tail * tail;
+    cost += 50ull * (unsigned long long)L;
+    cost >>= 6;   // (fits 32 bits for any read)
+    st.costEst = (uint32_t)min(cost, 0xFFFFFFFFull);
+  }
   if (l == 0) state[r] = st;
   if (trace.recs && r == traceRead && l == 0) {
     uint32_t k = atomicAdd(trace.nrec, 1u);
@@ -2380,6 +2404,39 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     }
 #endif
   }
+}
+
+// ==================================================================== work-queue order
+// Reads by descending cost estimate, without a sort: a 1024-bucket counting sort on a 10-bit logarithmic key (the order
+// inside a bucket is whatever the atomics make it: records do not depend on the order reads are taken in).
+TALC_D uint32_t order_bucket(const ReadState& st) {
+  if (st.status != TALC_READ_CORRECTED || st.overflow) return 1023u;   // passed through: last
+  const uint32_t c = st.costEst | 1u;
+  const int e = 31 - __builtin_clz(c);                               // 0..31
+  const uint32_t m = (e >= 5) ? ((c >> (e - 5)) & 31u) : ((c << (5 - e)) & 31u);
+  return 1022u - min(1022u, (uint32_t)e * 32u + m);                  // heavy first
+}
+__global__ void k_order_hist(const ReadState* __restrict__ state, uint32_t n, uint32_t* __restrict__ hist) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) atomicAdd(&hist[order_bucket(state[r])], 1u);
+}
+__global__ void __launch_bounds__(1024) k_order_scan(uint32_t* __restrict__ hist) {   // hist[b] := first position of bucket b
+  __shared__ uint32_t s[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t v = hist[t];
+  s[t] = v;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t add = (t >= off) ? s[t - off] : 0u;
+    __syncthreads();
+    s[t] += add;
+    __syncthreads();
+  }
+  hist[t] = s[t] - v;
+}
+__global__ void k_order_scatter(const ReadState* __restrict__ state, uint32_t n, uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) order[atomicAdd(&cursor[order_bucket(state[r])], 1u)] = r;
 }
 
 // ==================================================================== k_pack
