@@ -111,7 +111,7 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   c.fullCap = 128 * scale;
   c.fullPool = (uint32_t)align_up(std::max<uint64_t>(65536, 4ull * c.seqCap) * scale, 16);
   c.dpCap = (uint32_t)align_up(std::max<uint64_t>(c.edgeCap, c.seqCap) + 8, 4);
-  if (c.dpCap < 1024) c.dpCap = 1024;   // (the phased x-drop keeps its hand-over state in these arrays)
+  if (c.dpCap < 2048) c.dpCap = 2048;   // (the phased x-drop keeps its hand-over state in these arrays)
   if (tiny) { c.anchCap = 3; c.fullCap = 1; c.fullPool = (uint32_t)align_up((uint64_t)c.seqCap, 16); }  // test hook: force the retry pass
   c.regCap = (uint32_t)(Lm / 2 + 4);
   c.weakPool = (uint32_t)align_up(out_capacity_for(Lm), 16);
@@ -922,8 +922,13 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 
 // growth-order restatement: the seed sits at the anchor end; extension starts at offset S
 // (K-1 walking RIGHT: Seed(0,0,K-1,K-1); K walking LEFT: Seed(len-K, len-K, len-1, len-1)).
-TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
-                                  bool withScore) {
+// WIDE: the instance for extensions whose x needs more than 255 diagonals (x beyond 127: the tail of a long edge, whose
+// x grows by 2 per scoring, Explorer.cpp:713) — a function of its own, entered by a tail call, so that the registers of
+// its eight-diagonals-per-lane phase (and the callee-saved ones it has to save) are paid by the few calls that get that
+// far, not by every extension.
+template <bool WIDE>
+TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
+                                       bool withScore) {
   PROF_DECL;
   refLen = uni(refLen); candLen = uni(candLen); xdrop = uni(xdrop); ref = uni_ptr(ref); cand = uni_ptr(cand);
   const int K = (int)X.P.K;
@@ -943,11 +948,31 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
     uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
     // furthest-reaching wavefronts, 1 / 2 / 4 diagonals per lane (x up to 31 / 63 / 127)
     const int ndiagonals = min(max(xdrop, 0), qlen) + min(max(xdrop, 0), dlen) + 1;
-    if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
-    else if (ndiagonals <= 255 && X.C.dpCap >= 1024u) {
+    if (WIDE) {
+      // in phases (WfaPhase): levels 0..31 one diagonal per lane, 32..63 two, 64..127 four, the rest eight.  (A 500-base
+      // edge ends near x = 210; without the eight-wide phase its last forty scorings per anchor fell back to the
+      // anti-diagonal sweep — most of the 40 ms of the heaviest reads of a batch, which is what the launch waits for.)
+      int* mem = X.dpG + 2ull * X.C.dpCap + 256;   // (past the flags of the multi-x run)
+      WfaPhase ph{-1, 31, mem, mem + 512};
+      rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+      if (rc == 2) {
+        ph.fromLevel = 31; ph.toLevel = 63;
+        rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+        if (rc == 2) {
+          ph.fromLevel = 63; ph.toLevel = 127;
+          rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+          if (rc == 2) {
+            ph.fromLevel = 127; ph.toLevel = -1;
+            rc = wave_xdrop_wfa<8>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+          }
+        }
+      }
+    }
+    else if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (ndiagonals <= 255 && X.C.dpCap >= 2048u) {
       // in phases (WfaPhase): levels 0..31 one diagonal per lane, 32..63 two, the rest four
       int* mem = X.dpG + 2ull * X.C.dpCap + 256;   // (past the flags of the multi-x run)
-      WfaPhase ph{-1, 31, mem, mem + 256};
+      WfaPhase ph{-1, 31, mem, mem + 512};
       rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
       if (rc == 2) {
         ph.fromLevel = 31; ph.toLevel = (ndiagonals <= 127) ? -1 : 63;
@@ -1003,6 +1028,22 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
     r.stop = true;
   }
   return r;
+}
+
+TALC_DN SeedExt seed_and_extension_wide(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
+  return seed_and_extension_body<true>(ref, refLen, cand, candLen, xdrop, withScore);
+}
+TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
+  {   // more than 255 diagonals (and a stage that takes the segments): the wide instance
+    const int rl = uni(refLen), cl = uni(candLen), x = max(uni(xdrop), 0);
+    const int S = uni(X.dirRight) ? (int)X.P.K - 1 : (int)X.P.K;
+    const int qlen = min(rl, cl) - S, dlen = max(rl, cl) - S;
+    if (qlen > 0 && dlen > 0) {
+      const int nd = min(x, qlen) + min(x, dlen) + 1;
+      if (nd > 255 && nd <= 511 && uni((int)X.C.dpCap) >= 2048) [[clang::musttail]] return seed_and_extension_wide(ref, refLen, cand, candLen, xdrop, withScore);
+    }
+  }
+  return seed_and_extension_body<false>(ref, refLen, cand, candLen, xdrop, withScore);
 }
 
 // getSeedAndExtension without the score (the form findStopPosition uses) from a given extension (extCols on the

@@ -496,7 +496,7 @@ TALC_D void stage_copy(uint8_t TALC_AS3* dst, gcu8 src, int n) {
 
 // Phases.  Level e only involves the diagonals |k| <= e, so a run whose x needs 2 or 4 diagonals per lane can take its
 // first 31 levels with one diagonal per lane, the next 32 with two, and only the rest at full width: a phase stops
-// after level `toLevel`, leaves the state in memory by diagonal (index k + 128), and the next, wider instance
+// after level `toLevel`, leaves the state in memory by diagonal (index k + 256), and the next, wider instance
 // continues from there (`fromLevel`).  The segments are staged once, by the first phase, for the run's real x.
 // Return value 2 = "to be continued"; a phase that reaches the far corner ends the whole run (return 1).
 struct WfaPhase {
@@ -576,8 +576,8 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     for (int s = 0; s < NR; ++s) {
       const int j = 64 * s + l, k = kmin + j, ak = k < 0 ? -k : k;
       const bool in = (j < nd) & (ak <= fromLevel);
-      F[s] = in ? ph->memF[in ? k + 128 : 128] : NEG;
-      E[s] = in ? ph->memE[in ? k + 128 : 128] : 0;
+      F[s] = in ? ph->memF[in ? k + 256 : 256] : NEG;
+      E[s] = in ? ph->memE[in ? k + 256 : 256] : 0;
     }
     eStart = fromLevel + 1;
   } else {
@@ -635,7 +635,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
       const int j = 64 * s + l, k = kmin + j, ak = k < 0 ? -k : k;
-      if ((j < nd) & (ak <= toLevel)) { ph->memF[k + 128] = F[s]; ph->memE[k + 128] = E[s]; }
+      if ((j < nd) & (ak <= toLevel)) { ph->memF[k + 256] = F[s]; ph->memE[k + 256] = E[s]; }
     }
     WSYNC();
     return 2;

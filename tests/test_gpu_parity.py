@@ -158,7 +158,7 @@ def test_device_seed_and_extension_matches_oracle(gpu_pair):
     rnd = random.Random(4)
     L = O.lib()
     ctx = gpu_pair.ctx
-    for it in range(120):
+    for it in range(160):
         n = rnd.choice([21, 22, 30, 80, 200, 600, 1400])
         ref = [rnd.choice("ACGT") for _ in range(n)]
         cand = list(ref)
@@ -177,7 +177,8 @@ def test_device_seed_and_extension_matches_oracle(gpu_pair):
             cand = cand + [rnd.choice("ACGT") for _ in range(rnd.randint(1, 40))]
         ref, cand = "".join(ref), "".join(cand)
         # <= ~30: band held in registers; above: LDS anti-diagonals (short segments) or HBM ones (long segments)
-        xdrop = rnd.randint(-1, 30) if rnd.random() < 0.6 else rnd.randint(31, 160)
+        # (up to 127: the phased wavefront; 128-255: its eight-diagonals-per-lane instance; beyond: anti-diagonal sweeps)
+        xdrop = rnd.randint(-1, 30) if rnd.random() < 0.5 else rnd.randint(31, 300)
         for direction in (0, 1):
             out = np.zeros(3, dtype=np.int64)
             stop = C.c_int32()
