@@ -1,0 +1,8 @@
+#!/bin/bash
+set -o pipefail
+O=gpurun_out
+python -m pytest tests -m gpu -x -q -k "edit_distance or default_parameters or golden or branching or reverse or junction or parameter_variants" > $O/r02p_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/r02p_pytest.log
+python bench.py --steps 6 --warmup 2 --no-cpu --no-h2h --no-paralog > $O/r02p_bench_c2.json 2> $O/r02p_bench_c2.err || exit 1
+grep -h "warmup 1" $O/r02p_bench_c2.err
+TALC_LIB=$PWD/talc_amd/_build/libtalc_hip_prof.so TALC_PROF_PRINT=1 python bench.py --steps 1 --warmup 1 --no-cpu --no-h2h --no-paralog > $O/r02p_prof.json 2> $O/r02p_prof.err || exit 1
+grep "prof\]" $O/r02p_prof.err | grep -E "evalfull|total|utilisation|maxread"

@@ -2324,8 +2324,9 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
           X.location = LOC_INNER; X.dirRight = (attempt == 0) ? 1 : 0;
           X.Ls = X.regS[reg]; X.Le = X.regE[reg]; X.Rs = X.regS[reg + 1]; X.Re = X.regE[reg + 1];
           X.weakLen = (X.Rs > X.Le + K) ? (X.Rs - (X.Le + K)) : 0;
-          build_anchors(0);
-          build_anchors(1);
+          // (the LEFT attempt after a failed RIGHT one starts from the same two regions — a failed search changes
+          //  neither — so anchorLEFTHandSide / anchorRIGHTHandSide, Explorer.cpp:239-240, would return the lists again)
+          if (attempt == 0) { build_anchors(0); build_anchors(1); }
           trace_search();
           PROF_BEGIN2(); success = search_bridge(wo, wl, weakUsed); PROF_END2(PF_SRCHB);
           if (X.tracing) {
