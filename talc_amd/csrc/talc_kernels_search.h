@@ -199,7 +199,7 @@ TALC_D int dev_out_degree(const TableView& T, uint32_t MINC, uint64_t kmer, uint
 // S(r) = sum of the r smallest IN counts (order statistics without sorting: the reference's sort only
 // feeds a trimmed sum, Read.cpp:505-512).  Counts below STRUCT_HBINS go through an LDS histogram (one
 // pass over the coverage, then a scan over the bins); larger ones through a bisection on the value.
-constexpr int STRUCT_HBINS = 2048, STRUCT_DEG_CAP = 1024;
+constexpr int STRUCT_HBINS = 1024, STRUCT_DEG_CAP = 512;   // (5 KB of LDS per wave: 32 waves per CU)
 TALC_D unsigned long long trimmed_prefix_sum(const uint2* __restrict__ cov, uint32_t n, uint32_t MINC, uint32_t r, uint32_t vmax) {
   if (r == 0) return 0ull;
   const int l = lane_id();
