@@ -213,3 +213,113 @@ def test_wavefront_xdrop_equals_antidiagonal_xdrop():
             assert (want[1:] == got[1:]).all(), (q, d, x, want.tolist(), got.tolist())
         seen[int(want[0])] += 1
     assert seen[1] > 1000
+
+
+# ---------------------------------------------------------------- bit-vector LCS / edit distance (wave_lcs_bitpar, wave_edit_bitpar)
+def _carries(G, P, W):
+    """Carry into each of W words from per-word generate / propagate bits: the formula of talc_wave.h."""
+    Y = (G << 1) & ((1 << W) - 1)
+    return (((Y + P) & ((1 << (W + 1)) - 1)) ^ P | Y) & ((1 << W) - 1)
+
+
+def test_cross_word_carry_formula_is_exact():
+    """((G << 1) + P) ^ P | (G << 1) gives the carry into every word of a multi-word addition when a word either
+    generates a carry or propagates one, never both — exhaustively for 10 words."""
+    W = 10
+    for G in range(1 << W):
+        for P in range(1 << W):
+            if G & P:
+                continue
+            c, exp = 0, 0
+            for l in range(W):
+                if c:
+                    exp |= 1 << l
+                c = ((G >> l) & 1) | (((P >> l) & 1) & c)
+            assert _carries(G, P, W) == exp, (bin(G), bin(P))
+
+
+def _multiword_add(V, U, nw):
+    """64-bit words, carries resolved with the ballot formula (what the lanes do)."""
+    M64 = (1 << 64) - 1
+    S = [(V[i] + U[i]) & M64 for i in range(nw)]
+    G = sum(1 << i for i in range(nw) if S[i] < V[i])
+    P = sum(1 << i for i in range(nw) if S[i] == M64)
+    C = _carries(G, P, nw)
+    return [(S[i] + ((C >> i) & 1)) & M64 for i in range(nw)]
+
+
+def _lcs_bitpar(a, b):
+    m = len(a)
+    nw = (m + 63) // 64
+    M64 = (1 << 64) - 1
+    pm = {c: [0] * nw for c in "ACGTN"}
+    for i, ch in enumerate(a):
+        pm[ch][i // 64] |= 1 << (i % 64)
+    V = [M64] * nw
+    for ch in b:
+        Mm = pm[ch]
+        U = [V[i] & Mm[i] for i in range(nw)]
+        S = _multiword_add(V, U, nw)
+        V = [S[i] | (V[i] & ~Mm[i] & M64) for i in range(nw)]
+    z = 0
+    for i in range(m):
+        z += 1 - ((V[i // 64] >> (i % 64)) & 1)
+    return z
+
+
+def _edit_bitpar(a, b):
+    m = len(a)
+    nw = (m + 63) // 64
+    M64 = (1 << 64) - 1
+    pm = {c: [0] * nw for c in "ACGTN"}
+    for i, ch in enumerate(a):
+        pm[ch][i // 64] |= 1 << (i % 64)
+    Pv, Mv, score = [M64] * nw, [0] * nw, m
+    tw, tb = (m - 1) // 64, (m - 1) % 64
+    for ch in b:
+        Eq = pm[ch]
+        Xv = [Eq[i] | Mv[i] for i in range(nw)]
+        S = _multiword_add(Pv, [Eq[i] & Pv[i] for i in range(nw)], nw)
+        Xh = [(S[i] ^ Pv[i]) | Eq[i] for i in range(nw)]
+        Ph = [Mv[i] | (~(Xh[i] | Pv[i]) & M64) for i in range(nw)]
+        Mh = [Pv[i] & Xh[i] for i in range(nw)]
+        score += (Ph[tw] >> tb) & 1
+        score -= (Mh[tw] >> tb) & 1
+        pc, mc = 1, 0                      # the border of a global alignment: +1 per column in row 0
+        for i in range(nw):
+            npc, nmc = Ph[i] >> 63, Mh[i] >> 63
+            Ph[i] = ((Ph[i] << 1) | pc) & M64
+            Mh[i] = ((Mh[i] << 1) | mc) & M64
+            pc, mc = npc, nmc
+        Pv = [Mh[i] | (~(Xv[i] | Ph[i]) & M64) for i in range(nw)]
+        Mv = [Ph[i] & Xv[i] for i in range(nw)]
+    return score
+
+
+def test_bit_vector_lcs_and_edit_distance_equal_the_oracle_alignments():
+    """The recurrences wave_lcs_bitpar / wave_edit_bitpar run (Hyyro's LCS, Myers' edit distance, words chained by
+    the carry formula) restated in Python, against the oracle's localAlignment(1,0,0) and -globalAlignment(0,-1,-1)."""
+    rnd = random.Random(77)
+    L = O.lib()
+    for it in range(60):
+        n = rnd.choice([1, 5, 63, 64, 65, 130, 200, 333])
+        a = [rnd.choice("ACGTN" if rnd.random() < 0.1 else "ACGT") for _ in range(n)]
+        if rnd.random() < 0.7:
+            b = []
+            for ch in a:
+                x = rnd.random()
+                if x < 0.05:
+                    b.append(rnd.choice("ACGT"))
+                elif x < 0.10:
+                    b.append(ch)
+                    b.append(rnd.choice("ACGT"))
+                elif x >= 0.15:
+                    b.append(ch)
+            b = b or ["A"]
+        else:
+            b = [rnd.choice("ACGT") for _ in range(rnd.choice([1, 7, 64, 150]))]
+        a, b = "".join(a), "".join(b)
+        exp_l = L.orc_global_alignment(a.encode(), b.encode(), 1, 0, 0, 0, 0, 0, 0)
+        exp_e = -L.orc_global_alignment(a.encode(), b.encode(), 0, -1, -1, 0, 0, 0, 0)
+        assert _lcs_bitpar(a, b) == exp_l and _lcs_bitpar(b, a) == exp_l, (len(a), len(b))
+        assert _edit_bitpar(a, b) == exp_e and _edit_bitpar(b, a) == exp_e, (len(a), len(b))
