@@ -22,7 +22,9 @@ ARCH = "gfx950"
 def _digest(sources, cmd):
     """Content hash of every source a target depends on plus the command line that builds it."""
     import hashlib
-    h = hashlib.sha256(" ".join(cmd).encode())
+    # (paths relative to the repo: the same tree gives the same stamp wherever it is checked out, so a binary built here
+    #  is recognised on the GPU box, whose copy lives under another path)
+    h = hashlib.sha256(" ".join(cmd).replace(ROOT, "$ROOT").encode())
     for s in sorted(sources):
         if os.path.exists(s):
             h.update(os.path.basename(s).encode())
