@@ -113,15 +113,23 @@ TALC_HD uint64_t table_home(uint64_t key, uint64_t cap) { return table_slot(tabl
 // false negatives by construction; a false positive only costs a bucket probe.
 //   * The hash is built from 24-bit multiplies (full rate on the vector unit; 32- and 64-bit integer multiplies are
 //     quarter rate, and the probe kernel turned out to be bound by them, not by memory).
-//   * TALC_FILTER_MINIMIZER = 1 chooses the block by the k-mer's minimizer (smallest hash among its K - M + 1 M-mers)
-//     instead of by the k-mer's own hash: consecutive k-mers of a read then share their block for (K - M + 1) / 2
-//     positions on average, so a wave probing consecutive positions touches a handful of 64-byte lines instead of 64.
-//     Measured on config 2 (profiles/r02): the extra M-mer hashing and window minimum cost more than the shared lines
-//     save, so it is off.
+//   * The BLOCK is chosen by the k-mer's minimizer (the smallest hash among its K - M + 1 M-mers), not by the k-mer's
+//     own hash: consecutive k-mers of a read share their minimizer, hence their 64-byte block, for (K - M + 2) / 2
+//     positions on average, and the lanes of a wave probe consecutive positions — their loads of one line become one
+//     request to the L2.  Measured on config 2: the filter part of the probe kernel is bound by the number
+//     of L2-missing requests (3.1 ms with one line per k-mer, 1.0 ms with shared lines).  M must be long enough that an
+//     M-mer is (nearly) unique in the transcriptome: with M = 11 (4 M possible M-mers for 54 M k-mers) every popular
+//     minimizer sent all its occurrences' k-mers to one block, the blocks' loads were badly skewed and the false
+//     positives — each a wasted bucket probe — cost more than the shared lines saved.  M = K - 7 clamped to [12, 16].
+//     TALC_FILTER_MINIMIZER = 0 builds the one-line-per-k-mer form (experiments).
 #ifndef TALC_FILTER_MINIMIZER
-#define TALC_FILTER_MINIMIZER 0
+#define TALC_FILTER_MINIMIZER 1
 #endif
-#define TALC_MINIMIZER_M 11
+TALC_HD uint32_t filter_mmer_len(uint32_t K) {
+  uint32_t m = K > 7 ? K - 7 : 1;
+  m = m < 12 ? 12 : (m > 16 ? 16 : m);
+  return m < K ? m : K;
+}
 TALC_HD uint32_t mul24(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __umul24(a, b);
@@ -129,19 +137,26 @@ TALC_HD uint32_t mul24(uint32_t a, uint32_t b) {
   return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
 #endif
 }
-TALC_HD uint32_t mmer_hash(uint32_t mmer) {   // 22-bit M-mer -> 32-bit hash (0xFFFFFFFF is reserved: "contains N")
-  uint32_t x = mul24(mmer, 0x9E3779u) ^ (mmer >> 7);
-  x ^= x >> 15; x = mul24(x, 0x85EBCBu) ^ (x >> 9); x ^= x >> 13;
+TALC_HD uint32_t mmer_hash(uint32_t mmer) {   // M-mer of up to 32 bits -> 32-bit hash (0xFFFFFFFF is reserved: "contains N")
+  uint32_t x = mul24(mmer, 0x9E3779u) ^ mul24(mmer >> 11, 0x85EBCBu) ^ (mmer >> 7);
+  x ^= x >> 15; x = mul24(x, 0xC2B2AFu) ^ (x >> 9); x ^= x >> 13;
   return x == 0xFFFFFFFFu ? 0xFFFFFFFEu : x;
 }
 // minimizer hash of a packed k-mer (first base most significant): the prober takes the same minimum from LDS
 TALC_HD uint32_t kmer_min_hash(uint64_t kmer, uint32_t K) {
+  const uint32_t M = filter_mmer_len(K);
+  const uint64_t mm = (M >= 32) ? ~0ULL : ((1ULL << (2 * M)) - 1);
   uint32_t best = 0xFFFFFFFFu;
-  for (uint32_t i = 0; i + TALC_MINIMIZER_M <= K; ++i) {
-    const uint32_t h = mmer_hash((uint32_t)(kmer >> (2 * (K - TALC_MINIMIZER_M - i))) & ((1u << (2 * TALC_MINIMIZER_M)) - 1));
+  for (uint32_t i = 0; i + M <= K; ++i) {
+    const uint32_t h = mmer_hash((uint32_t)((kmer >> (2 * (K - M - i))) & mm));
     best = h < best ? h : best;
   }
   return best;
+}
+// the block of a minimizer hash (the minimum of several hashes is not uniform: mixed again)
+TALC_HD uint64_t filter_block_of_min(uint32_t mh, uint64_t nBlocks) {
+  mh = mul24(mh, 0x2C1B3Du) ^ (mh >> 11); mh ^= mh >> 15; mh = mul24(mh, 0x297A2Du) ^ (mh >> 8);
+  return ((uint64_t)mh * nBlocks) >> 32;
 }
 // two 32-bit hash words of a k-mer: .x selects the block (unless by minimizer), .y the word and the three bits
 struct FilterHash { uint32_t x, y; };
@@ -158,9 +173,7 @@ TALC_HD FilterHash filter_hash(uint64_t kmer) {
 TALC_HD uint64_t filter_block(uint32_t h, uint64_t nBlocks) { return ((uint64_t)h * nBlocks) >> 32; }   // nBlocks < 2^32
 TALC_HD uint64_t filter_index(uint64_t kmer, uint32_t K, FilterHash h, uint64_t nBlocks) {
 #if TALC_FILTER_MINIMIZER
-  uint32_t mh = kmer_min_hash(kmer, K);   // (the minimum of several hashes is not uniform: mixed again)
-  mh = mul24(mh, 0xC2B2AFu) ^ (mh >> 11); mh ^= mh >> 15;
-  return filter_block(mh, nBlocks) * 8 + (h.y >> 29);
+  return filter_block_of_min(kmer_min_hash(kmer, K), nBlocks) * 8 + (h.y >> 29);
 #else
   return filter_block(h.x, nBlocks) * 8 + (h.y >> 29);
 #endif

@@ -196,8 +196,8 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
     return (nsh == 0) ? nlo : ((nlo >> nsh) | (nhi << (64 - nsh)));
   };
 #if TALC_FILTER_MINIMIZER
-  constexpr uint32_t M = TALC_MINIMIZER_M;
-  const uint32_t nmm = wlen - M + 1;                 // K >= 18 > M
+  const uint32_t M = filter_mmer_len(K);
+  const uint32_t nmm = wlen - M + 1;
   for (uint32_t q = threadIdx.x; q < nmm; q += COV_THREADS)
     s_mh[q] = (nbits(q) & ((1ull << M) - 1)) ? 0xFFFFFFFFu : mmer_hash((uint32_t)(window(q) >> (64 - 2 * M)));
   __syncthreads();
@@ -223,12 +223,15 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
 #if TALC_FILTER_MINIMIZER
         uint32_t mh = s_mh[p];
         for (uint32_t i = 1; i < nwin; ++i) mh = min(mh, s_mh[p + i]);
-        mh = mul24(mh, 0xC2B2AFu) ^ (mh >> 11); mh ^= mh >> 15;
-        const uint64_t idx = filter_block(mh, nBlocks) * 8 + (h.y >> 29);
+        const uint64_t idx = filter_block_of_min(mh, nBlocks) * 8 + (h.y >> 29);
 #else
         const uint64_t idx = filter_block(h.x, nBlocks) * 8 + (h.y >> 29);
 #endif
+#if defined(TALC_COV_EXP) && TALC_COV_EXP == 2   /* timing experiment: no filter traffic, the same share of survivors */
+        maybe = (h.x & 15u) == 0u; (void)idx; (void)m;
+#else
         maybe = (filter[idx] & m) == m;
+#endif
       }
 #if TALC_COV_QUEUE
       if (!maybe) out[p] = v2u32{0u, 0u};
@@ -249,7 +252,11 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   for (uint32_t qi = threadIdx.x; qi < qn; qi += COV_THREADS) {
     const uint32_t p = s_queue[qi];
     uint32_t c, j;
+#if defined(TALC_COV_EXP) && TALC_COV_EXP == 1   /* timing experiment: no table traffic */
+    c = 0; j = 0;
+#else
     cov_probe(T, window(p) >> kshift, min_count, c, j);
+#endif
     out[p] = v2u32{c, j};
     local_in += (c > min_count) ? 1 : 0;
   }
