@@ -404,7 +404,9 @@ int talc_table_upload(talc_table* t, int device) {
     HIPCHK(hipMemcpy(dc.left, t->h.left, bytes, hipMemcpyHostToDevice));
   }
   {   // presence filter, from the RIGHT table
-    dc.filterWords = (std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64) + 7) & ~7ull;   // whole 64-byte blocks
+    uint64_t bitsPerKmer = 20;   // (config 2: 10 bits 2.64 ms, 14 2.49, 20 2.39, 28 2.34 for k_coverage)
+    if (const char* e = getenv("TALC_FILTER_BITS")) bitsPerKmer = std::min<uint64_t>(64, std::max<uint64_t>(4, strtoull(e, nullptr, 10)));   // (experiments)
+    dc.filterWords = (std::max<uint64_t>(64, (t->h.nkmers * bitsPerKmer + 63) / 64) + 7) & ~7ull;   // whole 64-byte blocks
     HIPCHK(hipMalloc((void**)&dc.filter, dc.filterWords * 8));
     HIPCHK(hipMemset(dc.filter, 0, dc.filterWords * 8));
     if (t->h.capacity)

@@ -82,7 +82,7 @@ struct TableView {
   const Bucket* left;
   uint64_t capacity;     // buckets per table (any size below 2^32; home = table_home(key, capacity))
   uint32_t k;
-  // presence filter over the stored K-mers (blocked Bloom: three bits of one 64-bit word per k-mer, ~10 bits per
+  // presence filter over the stored K-mers (blocked Bloom: three bits of one 64-bit word per k-mer, ~20 bits per
   // k-mer, 64-byte blocks chosen by the k-mer's minimizer): small enough to stay in the last-level cache, it answers
   // most lookups of k-mers that are NOT in the table (93 % of a noisy read's k-mers) without touching the table.
   // nullptr / 0 = no filter.  filterWords is a multiple of 8.

@@ -37,6 +37,16 @@ TALC_D bool probe_bucket(const Bucket* tab, uint64_t cap, uint64_t key, BucketRe
   }
 }
 
+// the same, the home bucket `r` (slot i) having been loaded by the caller (several probes' first loads in flight together)
+TALC_D bool probe_bucket_from(const Bucket* tab, uint64_t cap, uint64_t key, uint64_t i, BucketRegs& r) {
+  while (true) {
+    if (r.key == key) return true;
+    if (r.key == kEmptyKey) return false;
+    if (++i == cap) i = 0;
+    r = load_bucket(tab + i);
+  }
+}
+
 // getCount (Jellyfish.cpp:407-413) for a packed K-mer
 TALC_D void dev_get_count(const TableView& T, uint64_t kmer, uint32_t& cnt, uint32_t& jc) {
   BucketRegs r;
@@ -106,24 +116,41 @@ __global__ void k_encode(const uint8_t* __restrict__ raw, uint8_t* __restrict__ 
 #define TALC_COV_QUEUE 1   /* 0: probe inside phase A (experiment) */
 #endif
 
-// the table part of one lookup: (count, colour | out-degrees) of a k-mer that passed the filter
-TALC_D void cov_probe(const TableView& T, uint64_t kmer, uint32_t min_count, uint32_t& c, uint32_t& j) {
+// The table part of one lookup, for a k-mer that passed the filter: its count and colour, and — for a k-mer of the
+// table — its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this MIN_COUNT), which ride in
+// the colour word's upper half: the anchor search asks for them position by position (Explorer.cpp:449,515) and would
+// otherwise probe, one dependent access at a time.  Three buckets are involved: RIGHT[prefix] (the count), LEFT[prefix]
+// (the predecessors' counts) and RIGHT[suffix] (the successors' counts) — and RIGHT[suffix] of position p is
+// RIGHT[prefix] of position p + 1, which that position's own lookup reads anyway when it is in the queue too (nine in
+// ten positions inside a solid region): cov_count publishes the successor degree its bucket implies for the position
+// before it, and cov_degrees only probes when nobody did.
+TALC_D uint32_t bucket_degree(const BucketRegs& r, uint32_t min_count) {
+  return (r.cnt[0] >= min_count) + (r.cnt[1] >= min_count) + (r.cnt[2] >= min_count) + (r.cnt[3] >= min_count);
+}
+// step 1: count, colour, left degree; degPrev = the right degree of the PREVIOUS position's k-mer
+TALC_D void cov_count(const TableView& T, uint64_t kmer, uint32_t min_count, uint32_t& c, uint32_t& j, uint32_t& dL, uint32_t& degPrev) {
+  c = 0; j = 0; dL = 0; degPrev = 0;
+  const uint64_t kp = kmer >> 2;
+  const uint64_t ip = dev_home(kp, T.capacity);
+  BucketRegs rc = load_bucket(T.right + ip), rl = load_bucket(T.left + ip);   // both requested before either is used
+  if (!probe_bucket_from(T.right, T.capacity, kp, ip, rc)) return;            // no successor of that (K-1)-mer at all
+  degPrev = bucket_degree(rc, min_count);
+  const int b = (int)(kmer & 3);
+  c = rc.cnt[b]; j = rc.jc(b);
+  if (c != 0 && probe_bucket_from(T.left, T.capacity, kp, ip, rl)) dL = bucket_degree(rl, min_count);
+}
+// step 2 (only for c != 0, when the next position did not publish it): the right degree by its own probe
+TALC_D uint32_t cov_right_degree(const TableView& T, uint64_t kmer, uint32_t min_count) {
   const uint32_t K = T.k;
-  c = 0; j = 0;
-  dev_get_count(T, kmer, c, j);
-  if (c != 0) {
-    // a k-mer of the table: its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this
-    // MIN_COUNT) ride in the colour word's upper half — the anchor search asks for them position by position
-    // (Explorer.cpp:449,515) and would otherwise probe, one dependent access at a time
-    const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
-    BucketRegs br;
-    uint32_t dR = 0, dL = 0;
-    if (probe_bucket(T.right, T.capacity, kmer & m1, br))
-      dR = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
-    if (probe_bucket(T.left, T.capacity, kmer >> 2, br))
-      dL = (br.cnt[0] >= min_count) + (br.cnt[1] >= min_count) + (br.cnt[2] >= min_count) + (br.cnt[3] >= min_count);
-    j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
-  }
+  const uint64_t m1 = (K >= 32) ? ~0ULL : ((1ULL << (2 * (K - 1))) - 1);
+  BucketRegs br;
+  return probe_bucket(T.right, T.capacity, kmer & m1, br) ? bucket_degree(br, min_count) : 0u;
+}
+// the unshared form (experiments: TALC_COV_QUEUE = 0)
+TALC_D void cov_probe(const TableView& T, uint64_t kmer, uint32_t min_count, uint32_t& c, uint32_t& j) {
+  uint32_t dL, degPrev;
+  cov_count(T, kmer, min_count, c, j, dL, degPrev);
+  if (c != 0) j |= kCovDegKnown | (cov_right_degree(T, kmer, min_count) << kCovDegRShift) | (dL << kCovDegLShift);
 }
 
 __global__ void __launch_bounds__(COV_THREADS)
@@ -137,6 +164,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   __shared__ uint32_t s_mh[COV_TILE + 64];                // hash of the M-mer starting at each window position
 #endif
   __shared__ uint16_t s_queue[COV_TILE];                  // positions whose k-mer passed the filter
+  __shared__ uint8_t s_degR[COV_TILE + 4];                // right degree of the k-mer at a position, published by the next position's lookup (0xFF: not)
   __shared__ uint32_t s_qn;
   __shared__ int s_nin;
   const uint32_t K = T.k;
@@ -150,6 +178,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   const uint8_t TALC_AS1* src = (const uint8_t TALC_AS1*)(codes + rb + p0);
 
   if (threadIdx.x == 0) { s_nin = 0; s_qn = 0; }
+  for (uint32_t i = threadIdx.x; i < (COV_TILE + 4) / 4; i += COV_THREADS) reinterpret_cast<uint32_t*>(s_degR)[i] = 0xFFFFFFFFu;
   // stage: 16 bases -> one u32 of 2-bit codes (first base in the top bits) + 16 N bits, per thread per pass
   {
     uint32_t* pk32 = reinterpret_cast<uint32_t*>(s_pack);
@@ -210,16 +239,20 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   const uint64_t TALC_AS1* filter = (const uint64_t TALC_AS1*)T.filter;
   v2u32 TALC_AS1* out = (v2u32 TALC_AS1*)(cov + koff[r] + p0);
   int local_in = 0;
-  // ---- phase A
-  for (uint32_t pb = 0; pb < cnt; pb += COV_THREADS) {
-    const uint32_t p = pb + threadIdx.x;
-    bool maybe = false;
-    if (p < cnt) {
-      maybe = (nbits(p) & nkmask) == 0;          // no N among bases [p, p+K)
-      if (maybe && filter) {
+  // ---- phase A.  The filter words of all of a thread's positions are requested before the first is looked at (a tile
+  // is at most COV_TILE / COV_THREADS = 8 positions per thread): one memory round trip per tile instead of one per pass.
+  constexpr int NPASS = COV_TILE / COV_THREADS;
+  uint64_t fword[NPASS], fmask[NPASS];
+#pragma unroll
+  for (int it = 0; it < NPASS; ++it) {
+    const uint32_t p = (uint32_t)it * COV_THREADS + threadIdx.x;
+    fword[it] = 0; fmask[it] = 1;                  // (p beyond the tile or an N in the k-mer: fails the test below)
+    if (p < cnt && (nbits(p) & nkmask) == 0) {     // no N among bases [p, p+K)
+      fword[it] = ~0ULL;
+      if (filter) {
         const uint64_t kmer = window(p) >> kshift;
         const FilterHash h = filter_hash(kmer);
-        const uint64_t m = filter_mask(h);
+        fmask[it] = filter_mask(h);
 #if TALC_FILTER_MINIMIZER
         uint32_t mh = s_mh[p];
         for (uint32_t i = 1; i < nwin; ++i) mh = min(mh, s_mh[p + i]);
@@ -228,11 +261,20 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
         const uint64_t idx = filter_block(h.x, nBlocks) * 8 + (h.y >> 29);
 #endif
 #if defined(TALC_COV_EXP) && TALC_COV_EXP == 2   /* timing experiment: no filter traffic, the same share of survivors */
-        maybe = (h.x & 15u) == 0u; (void)idx; (void)m;
+        fword[it] = ((h.x & 15u) == 0u) ? ~0ULL : 0ULL; (void)idx;
 #else
-        maybe = (filter[idx] & m) == m;
+        fword[it] = filter[idx];
 #endif
       }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NPASS; ++it) {
+    const uint32_t pb = (uint32_t)it * COV_THREADS;
+    if (pb >= cnt) break;
+    const uint32_t p = pb + threadIdx.x;
+    const bool maybe = (fword[it] & fmask[it]) == fmask[it];
+    if (p < cnt) {
 #if TALC_COV_QUEUE
       if (!maybe) out[p] = v2u32{0u, 0u};
     }
@@ -249,16 +291,32 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   __syncthreads();
   // ---- phase B
   const uint32_t qn = s_qn;
-  for (uint32_t qi = threadIdx.x; qi < qn; qi += COV_THREADS) {
-    const uint32_t p = s_queue[qi];
-    uint32_t c, j;
+  for (uint32_t qb = 0; qb < qn; qb += COV_THREADS) {   // (block-uniform trip count: the barrier inside is reached by all)
+    const uint32_t qi = qb + threadIdx.x;
+    const bool have = qi < qn;
+    uint32_t p = 0, c = 0, j = 0, dL = 0;
+    uint64_t kmer = 0;
+    if (have) {
+      p = s_queue[qi];
+      kmer = window(p) >> kshift;
 #if defined(TALC_COV_EXP) && TALC_COV_EXP == 1   /* timing experiment: no table traffic */
-    c = 0; j = 0;
+      (void)dL;
 #else
-    cov_probe(T, window(p) >> kshift, min_count, c, j);
+      uint32_t degPrev;
+      cov_count(T, kmer, min_count, c, j, dL, degPrev);
+      if (p > 0) s_degR[p - 1] = (uint8_t)degPrev;
 #endif
-    out[p] = v2u32{c, j};
-    local_in += (c > min_count) ? 1 : 0;
+    }
+    __syncthreads();
+    if (have) {
+      if (c != 0) {
+        uint32_t dR = s_degR[p];
+        if (dR == 0xFFu) dR = cov_right_degree(T, kmer, min_count);
+        j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
+      }
+      out[p] = v2u32{c, j};
+      local_in += (c > min_count) ? 1 : 0;
+    }
   }
 #else
       uint32_t c = 0, j = 0;
