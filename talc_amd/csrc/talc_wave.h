@@ -411,6 +411,52 @@ TALC_D unsigned long long lds_load_u64(const uint8_t TALC_AS3* p) {
   return v;
 }
 
+// Follow the match runs of the diagonals k = kmin + 64 s + lane from anti-diagonal a[s] (lanes with act[s] set), all
+// slots together: a[s] ends on the run's last anti-diagonal.  The segments are staged with a sentinel behind each (the
+// sentinels differ from each other and from every base, so every run ends) and 16 bytes of slack behind that.
+// Written without branches inside a slot (the number of equal leading bytes of two 8-byte words is a handful of
+// VALU ops): the first round compares eight bases — on a diagonal off the alignment a run is rarely longer than one or
+// two bases — the later rounds sixteen.
+TALC_D unsigned wfa_equal_prefix8(unsigned long long x, unsigned long long y) {   // number of equal leading (low) bytes, 0..8
+  const unsigned long long w = x ^ y;
+  const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+  // __ffs(0) = 0: the "- 1" makes an all-equal half 0xFFFFFFFF, which loses every min below
+  const unsigned t = min((unsigned)__ffs((int)lo) - 1u, ((unsigned)__ffs((int)hi) - 1u) | 32u);
+  return min(t >> 3, 8u);
+}
+template <int NR>
+TALC_D void wfa_extend(const uint8_t TALC_AS3* stage, int qpad, int kmin, int (&a)[NR], bool (&act)[NR]) {
+  const int l = lane_id();
+  unsigned qa[NR], da[NR];
+  bool any = false;
+#pragma unroll
+  for (int s = 0; s < NR; ++s) {
+    const int k = kmin + 64 * s + l;
+    qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
+    if (act[s]) {
+      const unsigned n = wfa_equal_prefix8(lds_load_u64(stage + qa[s]), lds_load_u64(stage + da[s]));
+      a[s] += 2 * (int)n; qa[s] += 8; da[s] += 8;
+      act[s] = (n == 8u);
+    }
+    any |= act[s];
+  }
+  while (ballot64(any) != 0ull) {
+    any = false;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      if (act[s]) {
+        const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
+        const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
+        const unsigned n0 = wfa_equal_prefix8(q0, d0), n1 = wfa_equal_prefix8(q1, d1);
+        const unsigned n = (n0 == 8u) ? 8u + n1 : n0;
+        a[s] += 2 * (int)n; qa[s] += 16; da[s] += 16;
+        act[s] = (n == 16u);
+        any |= act[s];
+      }
+    }
+  }
+}
+
 // ---- where the anti-diagonal loop of the original stops, and the cell it reports (talc_wfa.h), given the furthest
 // anti-diagonal F and its level E of every diagonal k = kmin + 64 s + lane.  Returns 0 when there is nothing to report.
 template <int NR>
@@ -541,33 +587,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     forb[s] = (ak == bmax + 1) ? ak : -1;   // the first border cell the x-drop leaves uninitialised
     F[s] = NEG; E[s] = 0;
   }
-  // follow the match run of diagonal k from anti-diagonal a (lanes with act set), all slots together
-  auto extend = [&](int (&a)[NR], bool (&act)[NR]) {
-    unsigned qa[NR], da[NR];
-    bool any = false;
-#pragma unroll
-    for (int s = 0; s < NR; ++s) {
-      const int k = kmin + 64 * s + l;
-      qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
-      any |= act[s];
-    }
-    // sixteen bases per round trip to the LDS (all four reads are issued before the first is used): the sentinels
-    // behind both segments end every run, and the stage leaves 16 bytes of slack behind each segment
-    while (ballot64(any) != 0ull) {
-      any = false;
-#pragma unroll
-      for (int s = 0; s < NR; ++s) {
-        if (act[s]) {
-          const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
-          const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
-          const unsigned long long w0 = q0 ^ d0, w1 = q1 ^ d1;
-          if (w0 != 0ull) { a[s] += 2 * (__builtin_ctzll(w0) >> 3); act[s] = false; }
-          else if (w1 != 0ull) { a[s] += 16 + 2 * (__builtin_ctzll(w1) >> 3); act[s] = false; }
-          else { qa[s] += 16; da[s] += 16; a[s] += 32; any = true; }
-        }
-      }
-    }
-  };
+  auto extend = [&](int (&a)[NR], bool (&act)[NR]) { wfa_extend<NR>(stage, qpad, kmin, a, act); };
   bool cornerHit = false;
   int cornerE = 0;
   int eStart = 1;
@@ -680,32 +700,7 @@ TALC_D int wave_xdrop_wfa_multi(const uint8_t* __restrict__ querySeg_, int qlen,
     amax[s] = (j < nd) ? min(2 * qlen - k, 2 * dlen + k) : NEG;
     F[s] = NEG; E[s] = 0;
   }
-  auto extend = [&](int (&a)[NR], bool (&act)[NR]) {
-    unsigned qa[NR], da[NR];
-    bool any = false;
-#pragma unroll
-    for (int s = 0; s < NR; ++s) {
-      const int k = kmin + 64 * s + l;
-      qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
-      any |= act[s];
-    }
-    // sixteen bases per round trip to the LDS (all four reads are issued before the first is used): the sentinels
-    // behind both segments end every run, and the stage leaves 16 bytes of slack behind each segment
-    while (ballot64(any) != 0ull) {
-      any = false;
-#pragma unroll
-      for (int s = 0; s < NR; ++s) {
-        if (act[s]) {
-          const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
-          const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
-          const unsigned long long w0 = q0 ^ d0, w1 = q1 ^ d1;
-          if (w0 != 0ull) { a[s] += 2 * (__builtin_ctzll(w0) >> 3); act[s] = false; }
-          else if (w1 != 0ull) { a[s] += 16 + 2 * (__builtin_ctzll(w1) >> 3); act[s] = false; }
-          else { qa[s] += 16; da[s] += 16; a[s] += 32; any = true; }
-        }
-      }
-    }
-  };
+  auto extend = [&](int (&a)[NR], bool (&act)[NR]) { wfa_extend<NR>(stage, qpad, kmin, a, act); };
   auto hits = [&](const int (&f)[NR]) -> bool {
     unsigned long long hit = 0;
 #pragma unroll
@@ -800,32 +795,7 @@ TALC_D int wave_wfa_global(const uint8_t TALC_AS3* stage, int qpad, int qlen, in
     amax[s] = (j < nd) ? min(2 * qlen - k, 2 * dlen + k) : NEG;
     F[s] = NEG;
   }
-  auto extend = [&](int (&a)[NR], bool (&act)[NR]) {
-    unsigned qa[NR], da[NR];
-    bool any = false;
-#pragma unroll
-    for (int s = 0; s < NR; ++s) {
-      const int k = kmin + 64 * s + l;
-      qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
-      any |= act[s];
-    }
-    // sixteen bases per round trip to the LDS (all four reads are issued before the first is used): the sentinels
-    // behind both segments end every run, and the stage leaves 16 bytes of slack behind each segment
-    while (ballot64(any) != 0ull) {
-      any = false;
-#pragma unroll
-      for (int s = 0; s < NR; ++s) {
-        if (act[s]) {
-          const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
-          const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
-          const unsigned long long w0 = q0 ^ d0, w1 = q1 ^ d1;
-          if (w0 != 0ull) { a[s] += 2 * (__builtin_ctzll(w0) >> 3); act[s] = false; }
-          else if (w1 != 0ull) { a[s] += 16 + 2 * (__builtin_ctzll(w1) >> 3); act[s] = false; }
-          else { qa[s] += 16; da[s] += 16; a[s] += 32; any = true; }
-        }
-      }
-    }
-  };
+  auto extend = [&](int (&a)[NR], bool (&act)[NR]) { wfa_extend<NR>(stage, qpad, kmin, a, act); };
   {
     int a0[NR]; bool act0[NR];
     const int j0 = -kmin;
