@@ -503,11 +503,12 @@ struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online 
 
 enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
        PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
-       PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX, PF_N };
+       PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX,
+       PF_XSTAGE, PF_XLEV, PF_XSEL, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
                        "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
                        "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords", "#reads<0.25ms", "#reads<1ms", "#reads<4ms", \
-                       "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)"}
+                       "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)", "x.stage", "x.levels", "x.select"}
 
 struct Wv {
   // kernel constants
@@ -2257,7 +2258,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   unsigned long long totCells = 0, totSteps = 0;
   PROF_DECL2;
 #ifdef TALC_PROF
-  if (l == 0) for (int i = 0; i < PF_N; ++i) g_prof[i] = 0;
+  if (l == 0) { for (int i = 0; i < PF_N; ++i) g_prof[i] = 0; for (int i = 0; i < 4; ++i) g_wprof[i] = 0; }
   const unsigned long long _pf_k0 = __builtin_amdgcn_s_memtime();
   const unsigned long long _pf_r0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
   unsigned long long _pf_rd0 = 0;
@@ -2433,6 +2434,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     if (totCells) atomicAdd((unsigned long long*)&counters[1], totCells);
 #ifdef TALC_PROF
     g_prof[PF_TOTAL] = __builtin_amdgcn_s_memtime() - _pf_k0;
+    g_prof[PF_XSTAGE] = g_wprof[0]; g_prof[PF_XLEV] = g_wprof[1]; g_prof[PF_XSEL] = g_wprof[2];
     {   // wave utilisation of the launch: sum of the waves' lifetimes against (last end - first start) x waves
       const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
       atomicAdd((unsigned long long*)&counters[61], r1 - _pf_r0);   // (counters[2 .. 2 + PF_N) are the categories)

@@ -551,6 +551,15 @@ struct WfaPhase {
   int* memF; int* memE;
 };
 
+#ifdef TALC_PROF
+__shared__ unsigned long long g_wprof[4];   // staging, levels, selection of wave_xdrop_wfa (category profile build)
+#define WPROF_T() __builtin_amdgcn_s_memtime()
+#define WPROF_ADD(i, t0) (g_wprof[i] += __builtin_amdgcn_s_memtime() - (t0))
+#else
+#define WPROF_T() 0ull
+#define WPROF_ADD(i, t0) ((void)(t0))
+#endif
+
 template <int NR>
 TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int x,
                           uint8_t TALC_AS3* stage, int stageCap, int& extCols, int& extRows, int& extScore,
@@ -571,12 +580,15 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   const int qS = min(qlen, dlen + X), dS = min(dlen, qlen + X);
   const int qpad = (qS + 16) & ~7;
   if (qpad + dS + 16 > stageCap) return -1;
+  const unsigned long long _t0 = WPROF_T();
   if (fromLevel < 0) {
     stage_copy(stage, querySeg, qS);
     stage_copy(stage + qpad, dbSeg, dS);
     if (l == 0) { stage[qS] = 0xF0; stage[qpad + dS] = 0xF1; }   // differ from each other and from every base code
   }
   WSYNC();
+  WPROF_ADD(0, _t0);
+  const unsigned long long _t1 = WPROF_T();
   const int bmax = x >= 2 ? x - 1 : (x == 1 ? 1 : 0);
   const int corner = qlen + dlen;
   int F[NR], E[NR], amax[NR], forb[NR];
@@ -650,6 +662,8 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     if (hit != 0ull) { cornerHit = true; cornerE = e; }
   }
   cells += work;
+  WPROF_ADD(1, _t1);
+  const unsigned long long _t2 = WPROF_T();
   if (cornerHit) { extCols = qlen; extRows = dlen; extScore = -cornerE; return 1; }
   if (toLevel >= 0 && toLevel < x) {   // hand over to the wider instance
 #pragma unroll
@@ -660,7 +674,9 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     WSYNC();
     return 2;
   }
-  return wfa_select<NR>(F, E, kmin, kmax, qlen, dlen, extCols, extRows, extScore);
+  const int rsel = wfa_select<NR>(F, E, kmin, kmax, qlen, dlen, extCols, extRows, extScore);
+  WPROF_ADD(2, _t2);
+  return rsel;
 }
 
 // ---- the same extension for EVERY drop-off x in [0, xHi] from one run (findStopPosition, Trajectory.cpp:482-503,
