@@ -578,11 +578,14 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   d.MAX_IN_COUNT = p->max_in_count; d.MAX_BORDER_PATHS = p->max_nb_border_paths; d.MAX_INNER_PATHS = p->max_nb_inner_paths;
   d.CHECK_INTERVAL = p->check_interval; d.FAILURE_RATE = p->allowed_failure_rate;
   d.MAX_BORDER_FAILURES = p->max_nb_border_failures; d.MAX_BORDER_LEN = p->max_border_length;
+  d.costEdgeLin = 2800; d.costEdgeQuad = 135;
+  if (const char* e = getenv("TALC_COST_LIN")) d.costEdgeLin = (uint32_t)strtoul(e, nullptr, 10);     // (tuning runs)
+  if (const char* e = getenv("TALC_COST_QUAD")) d.costEdgeQuad = (uint32_t)strtoul(e, nullptr, 10);
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&c->d_hist, 1024 * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&c->d_counters, 64 * sizeof(uint64_t)));
+  HIPCHK(hipMalloc((void**)&c->d_counters, 1088 * sizeof(uint64_t)));   // 64 counters + the profile build's log of slow reads
   *out = c;
   return TALC_OK;
 }

@@ -211,6 +211,8 @@ struct DevParams {
   double FAILURE_RATE;
   int32_t MAX_BORDER_FAILURES;
   uint32_t MAX_BORDER_LEN;
+  // work estimate of an edge of h bases, in wave-cycles (only the order of the work queue depends on it; k_structure)
+  uint32_t costEdgeLin, costEdgeQuad;
 };
 
 }  // namespace talc

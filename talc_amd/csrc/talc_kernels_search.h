@@ -51,7 +51,7 @@ __host__ __device__ inline uint64_t out_capacity_for(uint64_t L) { return 4 * L 
 struct FullMeta { uint32_t off, len; int32_t lanc, ranc; double dist; };
 
 // per-wave scratch layout (byte offsets inside one slot)
-struct SearchCaps {
+struct SearchLimits {   // (the part the search itself consults: a copy lives in the wave's LDS)
   uint32_t seqCap;      // bytes per Trail sequence (host: the longest possible; device: the current search's stride)
   uint32_t seqArena;    // bytes of the arena the Trail buffers are cut from
   uint32_t refCap;      // bytes of currentRefSeq
@@ -62,6 +62,8 @@ struct SearchCaps {
   uint32_t dpCap;       // ints per HBM DP array
   uint32_t regCap;      // regions per read
   uint32_t weakPool;    // bytes for corrected weak sequences
+};
+struct SearchCaps : SearchLimits {
   uint64_t slotBytes;
   uint64_t o_setA, o_setB, o_seqPool, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
       o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak;
@@ -92,8 +94,7 @@ struct TrailSetLayout {
 // whose arena holds NBUF buffers of the longest possible Trail and whose counted capacities (anchors, recorded
 // bridges) are multiplied by `scale`.  arenaLimit (first pass only; 0 = the default) is a test hook.
 static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, uint32_t arenaLimit, bool tiny = false) {
-  SearchCaps c;
-  memset(&c, 0, sizeof c);
+  SearchCaps c = SearchCaps();
   const uint64_t Lm = maxLen;
   c.seqCap = (uint32_t)align_up((uint64_t)(1.2 * (double)Lm) + 4ull * K + 64, 16);   // the longest Trail of any search
   const uint64_t fullArena = (uint64_t)NBUF * c.seqCap;
@@ -449,8 +450,8 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     unsigned long long cost = wave_sum_u64(part);
     const unsigned long long head = regS[0], eLast = regE[Rfinal - 1];
     const unsigned long long tail = (eLast + 1 < n) ? (unsigned long long)L - (eLast + K) : 0ull;
-    if (head > 0 && head <= P.MAX_BORDER_LEN) cost += 2800ull * head + 135ull * head * head;
-    if (tail > 0 && tail <= P.MAX_BORDER_LEN) cost += 2800ull * tail + 135ull * tail * tail;
+    if (head > 0 && head <= P.MAX_BORDER_LEN) cost += (unsigned long long)P.costEdgeLin * head + (unsigned long long)P.costEdgeQuad * head * head;
+    if (tail > 0 && tail <= P.MAX_BORDER_LEN) cost += (unsigned long long)P.costEdgeLin * tail + (unsigned long long)P.costEdgeQuad * tail * tail;
     cost += 50ull * (unsigned long long)L;
     cost >>= 6;   // (fits 32 bits for any read)
     st.costEst = (uint32_t)min(cost, 0xFFFFFFFFull);
@@ -512,7 +513,7 @@ enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN
 
 struct Wv {
   // kernel constants
-  DevParams P; TableView T; SearchCaps C;
+  DevParams P; TableView T; SearchLimits C;
   // read
   const uint8_t* read; uint32_t L, n; const uint2* cov; double lambda;
   // scratch
@@ -552,17 +553,18 @@ enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
 __shared__ Wv g_X;
 #define X g_X
 #ifdef TALC_PROF
-__shared__ unsigned long long g_prof[PF_N];
+__shared__ uint32_t g_prof[PF_N];   // per wave, in cycles: 2^32 cycles = 1.9 s (32 bits keep the build in the product's LDS size class:
+                                     // LDS is handed out in steps of 1280 bytes, and one step more costs three of the 21 waves a CU holds)
 #endif
 
 // ---- optional in-kernel cycle accounting (diagnostic build only: -DTALC_PROF) ----
 #ifdef TALC_PROF
 #define PROF_DECL unsigned long long _pf_t
 #define PROF_BEGIN() (_pf_t = __builtin_amdgcn_s_memtime())
-#define PROF_END(cat) (g_prof[cat] += __builtin_amdgcn_s_memtime() - _pf_t)
+#define PROF_END(cat) (g_prof[cat] += (uint32_t)(__builtin_amdgcn_s_memtime() - _pf_t))
 #define PROF_DECL2 unsigned long long _pf_t2
 #define PROF_BEGIN2() (_pf_t2 = __builtin_amdgcn_s_memtime())
-#define PROF_END2(cat) (g_prof[cat] += __builtin_amdgcn_s_memtime() - _pf_t2)
+#define PROF_END2(cat) (g_prof[cat] += (uint32_t)(__builtin_amdgcn_s_memtime() - _pf_t2))
 #else
 #define PROF_DECL
 #define PROF_BEGIN() ((void)0)
@@ -1718,7 +1720,7 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
   g_bloom[l + 64] = ((unsigned long long)(uint32_t)bxHi << 32) | (uint32_t)bxLo;
   stepCounter_ = sc0 + (uint32_t)done;
 #ifdef TALC_PROF
-  if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (unsigned long long)done; }
+  if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (uint32_t)done; }
 #endif
   if (done) {
     X.steps += (unsigned long long)done;
@@ -1805,11 +1807,16 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
   uint32_t hh = (uint32_t)(table_hash(key) >> 32);
   PROF_END2(PF_FFENTRY);
+  // The record a Trail reaches when it takes all of the current record's steps is requested as soon as the lanes have
+  // hashed their tips — before the filter query, the aim check and the commit — so that its latency runs under that work.
+  uint32_t ePre = 0;
+  bool havePre = false;
   while (done < maxSteps) {
     if (done - flushed > 64 - TALC_WALK_LEVELS) flush();
     PROF_BEGIN();
     uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
-    uint32_t e = wtab[slot * 16 + laneOff];
+    uint32_t e = havePre ? ePre : wtab[slot * 16 + laneOff];
+    havePre = false;
     bool found = true;
     while (true) {   // linear probing, as in the bucket table (same slots)
       const uint64_t bk = ((uint64_t)(uint32_t)lane_get((int)e, TALC_WALK_LEVELS + 1) << 32) | (uint32_t)lane_get((int)e, TALC_WALK_LEVELS);
@@ -1841,6 +1848,10 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     else km = ((uint64_t)pre << (2 * (K - 1 - (uint32_t)lj))) | (kmer >> (2 * (lj + 1)));
     const uint64_t key2 = dirRight ? (km & m1) : (km >> 2);
     const uint32_t hv = (uint32_t)(table_hash(key2) >> 32);   // the filter hash of the new tip = the hash of its probe
+    {
+      const uint64_t slotN = ((uint64_t)(uint32_t)lane_get((int)hv, TALC_WALK_LEVELS - 1) * (uint64_t)(uint32_t)cap) >> 32;
+      ePre = wtab[slotN * 16 + laneOff];
+    }
     // possible cycle inside the record: the same hash on a lower lane
     bool dup = dpp_row_shr<1>(hv, ~hv) == hv;
     dup |= dpp_row_shr<2>(hv, ~hv) == hv;
@@ -1884,6 +1895,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     kmer = ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(km >> 32), last) << 32) | (uint32_t)lane_get((int)(uint32_t)km, last);
     key = dirRight ? (kmer & m1) : (kmer >> 2);
     hh = (uint32_t)lane_get((int)hv, last);
+    havePre = (last == TALC_WALK_LEVELS - 1);   // the requested record is the one the next round starts with
     cnt = (uint32_t)lane_get((int)top, last);
     done += nTake;
     LSYNC();
@@ -1913,7 +1925,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   flush();
   stepCounter_ = sc0 + (uint32_t)done;
 #ifdef TALC_PROF
-  if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (unsigned long long)done; }
+  if (l == 0) { g_prof[PF_NCALLS] += 1; g_prof[PF_NSTEPS] += (uint32_t)done; }
 #endif
   if (done) {
     X.steps += (unsigned long long)done;
@@ -2233,7 +2245,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   __shared__ uint32_t s_next;
   const int l = lane_id();
   uint8_t* slot = scratchAll + (uint64_t)blockIdx.x * C.slotBytes;
-  X.P = P; X.T = T; X.C = C;
+  X.P = P; X.T = T; X.C = (const SearchLimits&)C;
   X.G[0] = make_set(slot + C.o_setA);
   X.G[1] = make_set(slot + C.o_setB);
   X.ia = 0;
@@ -2262,6 +2274,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   const unsigned long long _pf_k0 = __builtin_amdgcn_s_memtime();
   const unsigned long long _pf_r0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
   unsigned long long _pf_rd0 = 0;
+  uint32_t _pf_prevQi = 0, _pf_prevR = 0;
 #endif
 
   while (true) {
@@ -2275,12 +2288,20 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - _pf_rd0;
       const int bk = dt < 25000ull ? 0 : dt < 100000ull ? 1 : dt < 400000ull ? 2 : dt < 1600000ull ? 3 : dt < 6400000ull ? 4 : 5;
       g_prof[PF_RD0 + bk] += 1;
-      if (dt > g_prof[PF_RDMAX]) g_prof[PF_RDMAX] = dt;
+      if (dt > g_prof[PF_RDMAX]) g_prof[PF_RDMAX] = (uint32_t)dt;
+      if (dt >= 600000ull && _pf_rd0 - _pf_r0 > 1500000ull) {   // a read of 6 ms or more that started 15 ms or more into the launch:
+        // (queue position, read), (start, duration) into the log behind the counters (TALC_PROF_SLOW prints it)
+        const unsigned long long k = atomicAdd((unsigned long long*)&counters[64], 1ull);
+        if (k < 480ull) { counters[65 + 2 * k] = ((unsigned long long)_pf_prevQi << 32) | _pf_prevR; counters[66 + 2 * k] = ((_pf_rd0 & 0xFFFFFFFFull) << 32) | (dt & 0xFFFFFFFFull); }
+      }
     }
     _pf_rd0 = __builtin_amdgcn_s_memrealtime();
 #endif
     PROF_BEGIN2();
     const uint32_t r = order[qi];
+#ifdef TALC_PROF
+    _pf_prevQi = qi; _pf_prevR = r;
+#endif
     const uint64_t rb = offsets[r];
     const uint32_t L = (uint32_t)(offsets[r + 1] - rb);
     uint8_t* out = outAll + outoff[r];
@@ -2433,7 +2454,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     if (totSteps) atomicAdd((unsigned long long*)&counters[0], totSteps);
     if (totCells) atomicAdd((unsigned long long*)&counters[1], totCells);
 #ifdef TALC_PROF
-    g_prof[PF_TOTAL] = __builtin_amdgcn_s_memtime() - _pf_k0;
+    g_prof[PF_TOTAL] = (uint32_t)(__builtin_amdgcn_s_memtime() - _pf_k0);
     g_prof[PF_XSTAGE] = g_wprof[0]; g_prof[PF_XLEV] = g_wprof[1]; g_prof[PF_XSEL] = g_wprof[2];
     {   // wave utilisation of the launch: sum of the waves' lifetimes against (last end - first start) x waves
       const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -2443,8 +2464,8 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       static_assert(2 + PF_N <= 61, "the profile categories run into the utilisation counters");
     }
     for (int i = 0; i < PF_N; ++i) {
-      if (i == PF_RDMAX) atomicMax((unsigned long long*)&counters[2 + i], g_prof[i]);
-      else atomicAdd((unsigned long long*)&counters[2 + i], g_prof[i]);
+      if (i == PF_RDMAX) atomicMax((unsigned long long*)&counters[2 + i], (unsigned long long)g_prof[i]);
+      else atomicAdd((unsigned long long*)&counters[2 + i], (unsigned long long)g_prof[i]);
     }
 #endif
   }

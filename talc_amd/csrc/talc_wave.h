@@ -552,9 +552,9 @@ struct WfaPhase {
 };
 
 #ifdef TALC_PROF
-__shared__ unsigned long long g_wprof[4];   // staging, levels, selection of wave_xdrop_wfa (category profile build)
+__shared__ uint32_t g_wprof[4];   // staging, levels, selection of wave_xdrop_wfa (category profile build)
 #define WPROF_T() __builtin_amdgcn_s_memtime()
-#define WPROF_ADD(i, t0) (g_wprof[i] += __builtin_amdgcn_s_memtime() - (t0))
+#define WPROF_ADD(i, t0) (g_wprof[i] += (uint32_t)(__builtin_amdgcn_s_memtime() - (t0)))
 #else
 #define WPROF_T() 0ull
 #define WPROF_ADD(i, t0) ((void)(t0))
