@@ -137,7 +137,7 @@ uint64_t talc_table_size(const talc_table* t);        /* SR_DBG.size() (main.cpp
 /* Device memory of one uploaded copy: the two bucket tables and the presence filter, plus the walk tables
  * (2 * capacity * 64 bytes: the fast-forward's lookahead records) once an upload has built them.  An upload
  * builds them when they leave a reserve (64 GB, or a quarter of the device if that is less) to the correction batches
- * and are themselves below 96 GB (beyond that they were measured slower than probing per step);
+ * (500 M k-mers: 70 GB of buckets + 141 GB of walk records on a 288 GB device);
  * the environment variable TALC_WALK=0 turns them off, TALC_WALK=1 makes their allocation mandatory. */
 uint64_t talc_table_device_bytes(const talc_table* t);
 

@@ -416,18 +416,18 @@ int talc_table_upload(talc_table* t, int device) {
     HIPCHK(hipDeviceSynchronize());
   }
   // walk tables (WalkEntry, talc_common.h): twice the bucket tables' size again.  Built when they leave the correction
-  // batches and their scratch a reserve (64 GB, or a quarter of the device if that is less) AND stay below 96 GB:
-  // measured on config 5 (547 M k-mers: 70 GB of buckets + 141 GB of walk records) the search is 20-30 % SLOWER with
-  // them than with the per-step probes (1341-1423 ms against 1100 ms per 100 k reads; profiles/r02) — dependent random
-  // reads over a 211 GB footprint cost more per access than they save in number — while at 84 GB in all (config 3/4)
-  // and 21 GB (config 2) they pay.  TALC_WALK=0 turns them off, TALC_WALK=1 insists.
+  // batches and their scratch a reserve (64 GB, or a quarter of the device if that is less).  Measured on config 5
+  // (547 M k-mers: 70 GB of buckets + 141 GB of walk records = 211 GB of the 288): search 187 ms with them against
+  // 228-242 ms with the per-step probes (profiles/r02; an earlier build of this round had measured the opposite, before
+  // the 8192-bit cycle filter — a record is cut at every false alarm — and kept them below 96 GB only).
+  // TALC_WALK=0 turns them off, TALC_WALK=1 insists.
   {
     const char* env = getenv("TALC_WALK");
     const uint64_t wbytes = t->h.capacity * sizeof(WalkEntry);
     size_t freeB = 0, totalB = 0;
     HIPCHK(hipMemGetInfo(&freeB, &totalB));
     const uint64_t reserve = std::min<uint64_t>(64ull << 30, (uint64_t)totalB / 4);
-    const bool want = env ? atoi(env) != 0 : ((uint64_t)freeB >= 2 * wbytes + reserve && 2 * wbytes <= (96ull << 30));
+    const bool want = env ? atoi(env) != 0 : ((uint64_t)freeB >= 2 * wbytes + reserve);
     if (want && t->h.capacity) {
       if (hipMalloc((void**)&dc.walkRight, wbytes) != hipSuccess || hipMalloc((void**)&dc.walkLeft, wbytes) != hipSuccess) {
         (void)hipGetLastError();
