@@ -585,7 +585,7 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&c->d_hist, 1024 * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&c->d_counters, 1088 * sizeof(uint64_t)));   // 64 counters + the profile build's log of slow reads
+  HIPCHK(hipMalloc((void**)&c->d_counters, (64 + 2 * 8192) * sizeof(uint64_t)));   // 64 counters + the profile build's record of every wave's last read
   *out = c;
   return TALC_OK;
 }

@@ -659,14 +659,17 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
     WSYNC();
   }
   if (haveEdit && haveLcs) return;
-  if (!haveLcs) {   // long or dissimilar sequences: the bit-vector LCS (exact; up to 4096 columns)
+  // long or dissimilar sequences: the bit-vector LCS and edit distance (exact; columns beyond 4096 in blocks whose
+  // hand-over bits — one or two per row — go through the first HBM DP array)
+  unsigned long long* const work = ((uint64_t)(max(la, lb) + 63) / 64 * 2 * 8 <= (uint64_t)X.C.dpCap * 4) ? (unsigned long long*)X.dpG : nullptr;
+  if (!haveLcs) {
     unsigned long long ncells = 0;
-    const int z = wave_lcs_bitpar(a, la, b, lb, ncells);
+    const int z = wave_lcs_bitpar(a, la, b, lb, ncells, work);
     if (z >= 0) { lcsLen = z; haveLcs = true; X.cells += ncells; }
   }
-  if (!haveEdit) {  // ... and the bit-vector edit distance
+  if (!haveEdit) {
     unsigned long long ncells = 0;
-    const int ed = wave_edit_bitpar(a, la, b, lb, ncells);
+    const int ed = wave_edit_bitpar(a, la, b, lb, ncells, work);
     if (ed >= 0) { editScore = -ed; haveEdit = true; X.cells += ncells; }
   }
   if (haveEdit && haveLcs) return;
@@ -2289,11 +2292,6 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       const int bk = dt < 25000ull ? 0 : dt < 100000ull ? 1 : dt < 400000ull ? 2 : dt < 1600000ull ? 3 : dt < 6400000ull ? 4 : 5;
       g_prof[PF_RD0 + bk] += 1;
       if (dt > g_prof[PF_RDMAX]) g_prof[PF_RDMAX] = (uint32_t)dt;
-      if (dt >= 600000ull && _pf_rd0 - _pf_r0 > 1500000ull) {   // a read of 6 ms or more that started 15 ms or more into the launch:
-        // (queue position, read), (start, duration) into the log behind the counters (TALC_PROF_SLOW prints it)
-        const unsigned long long k = atomicAdd((unsigned long long*)&counters[64], 1ull);
-        if (k < 480ull) { counters[65 + 2 * k] = ((unsigned long long)_pf_prevQi << 32) | _pf_prevR; counters[66 + 2 * k] = ((_pf_rd0 & 0xFFFFFFFFull) << 32) | (dt & 0xFFFFFFFFull); }
-      }
     }
     _pf_rd0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -2461,6 +2459,11 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       atomicAdd((unsigned long long*)&counters[61], r1 - _pf_r0);   // (counters[2 .. 2 + PF_N) are the categories)
       atomicMin((unsigned long long*)&counters[62], _pf_r0);
       atomicMax((unsigned long long*)&counters[63], r1);
+      // the wave's last read: (queue position, read), (its start, the wave's end) — TALC_PROF_SLOW prints the waves that end last
+      if (blockIdx.x < 8192u) {
+        counters[64 + 2 * blockIdx.x] = ((unsigned long long)_pf_prevQi << 32) | _pf_prevR;
+        counters[65 + 2 * blockIdx.x] = ((_pf_rd0 & 0xFFFFFFFFull) << 32) | (r1 & 0xFFFFFFFFull);
+      }
       static_assert(2 + PF_N <= 61, "the profile categories run into the utilisation counters");
     }
     for (int i = 0; i < PF_N; ++i) {

@@ -884,58 +884,78 @@ TALC_D unsigned long long load_u64_unaligned_fwd(gcu8 p) {
 // the carries into the lanes are ((G << 1) + P) ^ P | (G << 1)  (verified exhaustively; tests/test_pure_vs_oracle.py).
 // About 40 instructions per ROW whatever the number of columns, against cells / 64 for the lane-skewed DP and
 // levels x diagonals for the wavefront forms: this is the routine for sequences beyond a few hundred bases (K = 31
-// gaps, config 5).  Equal codes match (N with N, like Score<int,Simple>).  Returns -1 if neither sequence
-// fits 4096 columns.
-TALC_D int wave_lcs_bitpar(const uint8_t* __restrict__ a_, int la, const uint8_t* __restrict__ b_, int lb, unsigned long long& cells) {
+// gaps, config 5).  Equal codes match (N with N, like Score<int,Simple>).
+// this lane's match masks (one per code) of the 64 columns [c0, c0 + 64) of cs[0, m)
+TALC_D void bitpar_masks(gcu8 cs, int m, int c0, unsigned long long& pm0, unsigned long long& pm1, unsigned long long& pm2,
+                         unsigned long long& pm3, unsigned long long& pm4) {
+  pm0 = pm1 = pm2 = pm3 = pm4 = 0;
+  for (int w = 0; w < 8; ++w) {
+    const int base = c0 + 8 * w;
+    if (base >= m) break;
+    unsigned long long bytes = 0;
+    if (base + 8 <= m) bytes = load_u64_unaligned_fwd(cs + base);
+    else for (int i = 0; base + i < m; ++i) bytes |= (unsigned long long)cs[base + i] << (8 * i);
+    const int nb = min(8, m - base);
+    for (int i = 0; i < nb; ++i) {
+      const unsigned c = (unsigned)(bytes >> (8 * i)) & 0xFFu;
+      const unsigned long long bit = 1ull << (8 * w + i);
+      pm0 |= (c == 0u) ? bit : 0ull; pm1 |= (c == 1u) ? bit : 0ull; pm2 |= (c == 2u) ? bit : 0ull;
+      pm3 |= (c == 3u) ? bit : 0ull; pm4 |= (c == 4u) ? bit : 0ull;
+    }
+  }
+}
+
+// Sequences beyond 4096 columns (the gaps of 20 kb reads are searched with Trails of up to 24 k bases): the columns are
+// taken in blocks of 4096, block after block over all rows; what a block hands to the next is one carry bit per row,
+// kept in `work` ((rows + 63) / 64 words of global memory; nullptr: one block only, -1 beyond).
+TALC_D int wave_lcs_bitpar(const uint8_t* __restrict__ a_, int la, const uint8_t* __restrict__ b_, int lb, unsigned long long& cells,
+                           unsigned long long* work_ = nullptr) {
   la = uni(la); lb = uni(lb);
   if (la == 0 || lb == 0) return 0;
-  // columns = the longer sequence if it fits (the cost is per row), else the shorter one
+  unsigned long long* const work = (unsigned long long*)uni_ptr(work_);
+  // the cost is per row and block of columns: columns = whichever sequence makes blocks x rows smaller (the longer on a tie)
   const uint8_t* colp = uni_ptr(a_); int m = la; const uint8_t* rowp = uni_ptr(b_); int n = lb;
-  if ((la < lb && lb <= 4096) || la > 4096) { colp = uni_ptr(b_); m = lb; rowp = uni_ptr(a_); n = la; }
-  if (m > 4096) return -1;
+  {
+    const long long costA = (long long)((la + 4095) >> 12) * lb, costB = (long long)((lb + 4095) >> 12) * la;
+    if (costB < costA || (costB == costA && lb > la)) { colp = uni_ptr(b_); m = lb; rowp = uni_ptr(a_); n = la; }
+  }
+  const int nblk = (m + 4095) >> 12;
+  if (nblk > 1 && !work) return -1;
   cells += (unsigned long long)la * (unsigned long long)lb;
   gcu8 cs = (gcu8)colp; gcu8 rs = (gcu8)rowp;
   const int l = lane_id_here();
-  // match masks of this lane's 64 columns, one per code
-  unsigned long long pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0, pm4 = 0;
-  {
-    const int c0 = 64 * l;
-    for (int w = 0; w < 8; ++w) {
-      const int base = c0 + 8 * w;
-      if (base >= m) break;
-      unsigned long long bytes = 0;
-      if (base + 8 <= m) bytes = load_u64_unaligned_fwd(cs + base);
-      else for (int i = 0; base + i < m; ++i) bytes |= (unsigned long long)cs[base + i] << (8 * i);
-      const int nb = min(8, m - base);
-      for (int i = 0; i < nb; ++i) {
-        const unsigned c = (unsigned)(bytes >> (8 * i)) & 0xFFu;
-        const unsigned long long bit = 1ull << (8 * w + i);
-        pm0 |= (c == 0u) ? bit : 0ull; pm1 |= (c == 1u) ? bit : 0ull; pm2 |= (c == 2u) ? bit : 0ull;
-        pm3 |= (c == 3u) ? bit : 0ull; pm4 |= (c == 4u) ? bit : 0ull;
-      }
-    }
-  }
   const unsigned long long laneBit = 1ull << l;
-  unsigned long long V = ~0ull;
-  for (int j0 = 0; j0 < n; j0 += 64) {
-    const int jn = min(64, n - j0);
-    const int bvec = (l < jn) ? (int)rs[j0 + l] : 0;
-    for (int jj = 0; jj < jn; ++jj) {
-      const int b = lane_get(bvec, jj);     // the row's base, wave-uniform
-      const unsigned long long M = (b == 0) ? pm0 : (b == 1) ? pm1 : (b == 2) ? pm2 : (b == 3) ? pm3 : pm4;
-      const unsigned long long U = V & M;
-      unsigned long long S = V + U;
-      const unsigned long long G = ballot64(S < V), P = ballot64(S == ~0ull);
-      const unsigned long long Y = G << 1;
-      const unsigned long long C = ((Y + P) ^ P) | Y;
-      S += (C & laneBit) ? 1ull : 0ull;
-      V = S | (V & ~M);
+  int z = 0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int c00 = blk << 12;
+    unsigned long long pm0, pm1, pm2, pm3, pm4;
+    bitpar_masks(cs, m, c00 + 64 * l, pm0, pm1, pm2, pm3, pm4);
+    unsigned long long V = ~0ull;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int jn = min(64, n - j0);
+      const int bvec = (l < jn) ? (int)rs[j0 + l] : 0;
+      const unsigned long long cinW = (blk > 0) ? uni64(work[j0 >> 6]) : 0ull;   // the carries out of the block before, row by row
+      unsigned long long coutW = 0;
+      for (int jj = 0; jj < jn; ++jj) {
+        const int b = lane_get(bvec, jj);     // the row's base, wave-uniform
+        const unsigned long long M = (b == 0) ? pm0 : (b == 1) ? pm1 : (b == 2) ? pm2 : (b == 3) ? pm3 : pm4;
+        const unsigned long long U = V & M;
+        unsigned long long S = V + U;
+        const unsigned long long G = ballot64(S < V), P = ballot64(S == ~0ull);
+        const unsigned long long Y = (G << 1) | ((cinW >> jj) & 1ull);
+        const unsigned long long C = ((Y + P) ^ P) | Y;
+        coutW |= (((G | (P & C)) >> 63) & 1ull) << jj;
+        S += (C & laneBit) ? 1ull : 0ull;
+        V = S | (V & ~M);
+      }
+      if (blk + 1 < nblk && l == 0) work[j0 >> 6] = coutW;
     }
+    // zeros among this block's column bits
+    const int mine = max(0, min(64, m - c00 - 64 * l));
+    const unsigned long long colMask = (mine >= 64) ? ~0ull : ((1ull << mine) - 1);
+    z += __popcll(~V & colMask);
+    if (blk + 1 < nblk) WSYNC();   // lane 0's words are read by every lane
   }
-  // zeros among the m column bits
-  const int mine = max(0, min(64, m - 64 * l));
-  const unsigned long long colMask = (mine >= 64) ? ~0ull : ((1ull << mine) - 1);
-  int z = __popcll(~V & colMask);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
   return z;
@@ -944,70 +964,74 @@ TALC_D int wave_lcs_bitpar(const uint8_t* __restrict__ a_, int la, const uint8_t
 // ------------------------------------------------------------------ bit-parallel edit distance (long sequences)
 // Global edit distance (= minus the globalAlignment score with match 0, mismatch -1, gap -1; Trail.cpp:422,
 // Trajectory.cpp:413) by Myers' bit-vector algorithm in Hyyro's formulation: the pattern's positions are the bits (lane l
-// holds bits [64 l, 64 l + 63], up to 4096), the other sequence is consumed base by base; Pv / Mv are the vertical
+// holds bits [64 l, 64 l + 63] of a block of 4096), the other sequence is consumed base by base; Pv / Mv are the vertical
 // +1 / -1 deltas of the current column, the horizontal delta of row 0 is +1 (the matrix border of a global alignment).
 // The addition's carry crosses the lanes as in wave_lcs_bitpar, the two shifts by one take the top bit of the lane
-// below.  About 60 instructions per base of the consumed sequence whatever the pattern's length.  -1: neither fits.
-TALC_D int wave_edit_bitpar(const uint8_t* __restrict__ a_, int la, const uint8_t* __restrict__ b_, int lb, unsigned long long& cells) {
+// below.  About 60 instructions per base of the consumed sequence and block.  A pattern beyond 4096 positions is taken
+// in blocks (Myers' block formulation): a block hands the next the horizontal delta of its last row, +1 / 0 / -1 per
+// consumed base, as two bit arrays in `work` (2 x (n + 63) / 64 words; nullptr: one block only, -1 beyond).
+TALC_D int wave_edit_bitpar(const uint8_t* __restrict__ a_, int la, const uint8_t* __restrict__ b_, int lb, unsigned long long& cells,
+                            unsigned long long* work_ = nullptr) {
   la = uni(la); lb = uni(lb);
   if (la == 0 || lb == 0) return la + lb;
+  unsigned long long* const work = (unsigned long long*)uni_ptr(work_);
   const uint8_t* patp = uni_ptr(a_); int m = la; const uint8_t* txtp = uni_ptr(b_); int n = lb;
-  if ((la < lb && lb <= 4096) || la > 4096) { patp = uni_ptr(b_); m = lb; txtp = uni_ptr(a_); n = la; }
-  if (m > 4096) return -1;
+  {
+    const long long costA = (long long)((la + 4095) >> 12) * lb, costB = (long long)((lb + 4095) >> 12) * la;
+    if (costB < costA || (costB == costA && lb > la)) { patp = uni_ptr(b_); m = lb; txtp = uni_ptr(a_); n = la; }
+  }
+  const int nblk = (m + 4095) >> 12;
+  if (nblk > 1 && !work) return -1;
   cells += (unsigned long long)la * (unsigned long long)lb;
   gcu8 ps = (gcu8)patp; gcu8 ts = (gcu8)txtp;
   const int l = lane_id_here();
-  unsigned long long pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0, pm4 = 0;
-  {
-    const int c0 = 64 * l;
-    for (int w = 0; w < 8; ++w) {
-      const int base = c0 + 8 * w;
-      if (base >= m) break;
-      unsigned long long bytes = 0;
-      if (base + 8 <= m) bytes = load_u64_unaligned_fwd(ps + base);
-      else for (int i = 0; base + i < m; ++i) bytes |= (unsigned long long)ps[base + i] << (8 * i);
-      const int nb = min(8, m - base);
-      for (int i = 0; i < nb; ++i) {
-        const unsigned c = (unsigned)(bytes >> (8 * i)) & 0xFFu;
-        const unsigned long long bit = 1ull << (8 * w + i);
-        pm0 |= (c == 0u) ? bit : 0ull; pm1 |= (c == 1u) ? bit : 0ull; pm2 |= (c == 2u) ? bit : 0ull;
-        pm3 |= (c == 3u) ? bit : 0ull; pm4 |= (c == 4u) ? bit : 0ull;
-      }
-    }
-  }
   const unsigned long long laneBit = 1ull << l;
-  const int topLane = (m - 1) >> 6, topBit = (m - 1) & 63;
-  unsigned long long Pv = ~0ull, Mv = 0ull;
+  const int nw = (n + 63) >> 6;
   int score = m;
-  for (int j0 = 0; j0 < n; j0 += 64) {
-    const int jn = min(64, n - j0);
-    const int bvec = (l < jn) ? (int)ts[j0 + l] : 0;
-    for (int jj = 0; jj < jn; ++jj) {
-      const int b = lane_get(bvec, jj);
-      const unsigned long long Eq = (b == 0) ? pm0 : (b == 1) ? pm1 : (b == 2) ? pm2 : (b == 3) ? pm3 : pm4;
-      const unsigned long long Xv = Eq | Mv;
-      const unsigned long long Xa = Eq & Pv;
-      unsigned long long S = Xa + Pv;
-      const unsigned long long G = ballot64(S < Pv), P = ballot64(S == ~0ull);
-      const unsigned long long Y = G << 1;
-      const unsigned long long C = ((Y + P) ^ P) | Y;
-      S += (C & laneBit) ? 1ull : 0ull;
-      const unsigned long long Xh = (S ^ Pv) | Eq;
-      unsigned long long Ph = Mv | ~(Xh | Pv);
-      unsigned long long Mh = Pv & Xh;
-      // the delta of the last row: bit m-1
-      const unsigned long long up = ballot64(l == topLane && ((Ph >> topBit) & 1ull)), dn = ballot64(l == topLane && ((Mh >> topBit) & 1ull));
-      score += (up != 0ull) ? 1 : 0;
-      score -= (dn != 0ull) ? 1 : 0;
-      // shift by one across the lanes: lane 0 takes the border's +1 (Ph) / 0 (Mh)
-      int pTop = (int)(Ph >> 63), mTop = (int)(Mh >> 63);
-      pTop = lane_shr1(pTop); mTop = lane_shr1(mTop);
-      if (l == 0) { pTop = 1; mTop = 0; }
-      Ph = (Ph << 1) | (unsigned long long)(unsigned)pTop;
-      Mh = (Mh << 1) | (unsigned long long)(unsigned)mTop;
-      Pv = Mh | ~(Xv | Ph);
-      Mv = Ph & Xv;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int c00 = blk << 12;
+    const bool lastBlk = blk + 1 == nblk;
+    unsigned long long pm0, pm1, pm2, pm3, pm4;
+    bitpar_masks(ps, m, c00 + 64 * l, pm0, pm1, pm2, pm3, pm4);
+    const int topPos = (lastBlk ? m - 1 - c00 : 4095), topLane = topPos >> 6, topBit = topPos & 63;
+    unsigned long long Pv = ~0ull, Mv = 0ull;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int jn = min(64, n - j0);
+      const int bvec = (l < jn) ? (int)ts[j0 + l] : 0;
+      // horizontal deltas entering this block's first row: the border's +1 for the first block
+      const unsigned long long hinP = (blk > 0) ? uni64(work[j0 >> 6]) : ~0ull, hinM = (blk > 0) ? uni64(work[nw + (j0 >> 6)]) : 0ull;
+      unsigned long long outP = 0, outM = 0;
+      for (int jj = 0; jj < jn; ++jj) {
+        const int b = lane_get(bvec, jj);
+        const unsigned long long Eq = (b == 0) ? pm0 : (b == 1) ? pm1 : (b == 2) ? pm2 : (b == 3) ? pm3 : pm4;
+        const unsigned hp = (unsigned)((hinP >> jj) & 1ull), hm = (unsigned)((hinM >> jj) & 1ull);
+        const unsigned long long Xv = Eq | Mv;
+        const unsigned long long Eqx = Eq | ((l == 0 && hm) ? 1ull : 0ull);   // a -1 entering row 0 acts like a match there
+        const unsigned long long Xa = Eqx & Pv;
+        unsigned long long S = Xa + Pv;
+        const unsigned long long G = ballot64(S < Pv), P = ballot64(S == ~0ull);
+        const unsigned long long Y = G << 1;
+        const unsigned long long C = ((Y + P) ^ P) | Y;
+        S += (C & laneBit) ? 1ull : 0ull;
+        const unsigned long long Xh = (S ^ Pv) | Eqx;
+        unsigned long long Ph = Mv | ~(Xh | Pv);
+        unsigned long long Mh = Pv & Xh;
+        // the delta of the block's last row
+        const unsigned long long up = ballot64(l == topLane && ((Ph >> topBit) & 1ull)), dn = ballot64(l == topLane && ((Mh >> topBit) & 1ull));
+        if (lastBlk) { score += (up != 0ull) ? 1 : 0; score -= (dn != 0ull) ? 1 : 0; }
+        else { outP |= (up != 0ull ? 1ull : 0ull) << jj; outM |= (dn != 0ull ? 1ull : 0ull) << jj; }
+        // shift by one across the lanes: lane 0 takes the delta that enters the block
+        int pTop = (int)(Ph >> 63), mTop = (int)(Mh >> 63);
+        pTop = lane_shr1(pTop); mTop = lane_shr1(mTop);
+        if (l == 0) { pTop = (int)hp; mTop = (int)hm; }
+        Ph = (Ph << 1) | (unsigned long long)(unsigned)pTop;
+        Mh = (Mh << 1) | (unsigned long long)(unsigned)mTop;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+      }
+      if (!lastBlk && l == 0) { work[j0 >> 6] = outP; work[nw + (j0 >> 6)] = outM; }
     }
+    if (!lastBlk) WSYNC();
   }
   return score;
 }

@@ -153,6 +153,41 @@ def test_device_edit_distance_and_lcs_match_oracle(gpu_pair):
             assert got[1] == exp_l or (got[1] == t and exp_l >= t), (len(a), len(b), t, int(got[1]), exp_l)
 
 
+def test_device_edit_distance_and_lcs_beyond_4096_columns(gpu_pair):
+    """The bit-vector routines take sequences beyond 4096 positions in blocks of 4096 columns (a 20 kb read's gap is
+    searched with Trails of up to 24 k bases): block boundaries at, just before and just after multiples of 4096, two to
+    four blocks, similar (12-20 % apart: the wavefront forms give up) and unrelated pairs, both argument orders, N bases."""
+    rnd = random.Random(131)
+    L = O.lib()
+    ctx = gpu_pair.ctx
+    sizes = [(4096, 4096), (4097, 4096), (8192, 8191), (8193, 5000), (9000, 9400), (12288, 12000), (13001, 700), (16500, 4100)]
+    for n, m in sizes:
+        a = [rnd.choice("ACGTN" if rnd.random() < 0.05 else "ACGT") for _ in range(n)]
+        if rnd.random() < 0.75:
+            b = []
+            rate = rnd.choice([0.12, 0.2])
+            for ch in a:
+                x = rnd.random()
+                if x < rate / 3:
+                    b.append(rnd.choice("ACGT"))
+                elif x < 2 * rate / 3:
+                    b.append(ch)
+                    b.append(rnd.choice("ACGT"))
+                elif x >= rate:
+                    b.append(ch)
+            b = (b + [rnd.choice("ACGT") for _ in range(max(0, m - len(b)))])[:m]
+        else:
+            b = [rnd.choice("ACGT") for _ in range(m)]
+        a, b = "".join(a), "".join(b)
+        exp_e = L.orc_global_alignment(a.encode(), b.encode(), 0, -1, -1, 0, 0, 0, 0)
+        exp_l = L.orc_global_alignment(a.encode(), b.encode(), 1, 0, 0, 0, 0, 0, 0)
+        for x, y in ((a, b), (b, a)):
+            got = ctx.test_dp(4, x, y)
+            assert got[5] == 0 and (got[0], got[1]) == (exp_e, exp_l), (len(x), len(y), got[:2].tolist(), exp_e, exp_l)
+        got = ctx.test_dp(4, a, b, p0=1)
+        assert got[5] == 0 and (got[0], got[1]) == (0, exp_l), (n, m, got[:2].tolist(), exp_l)
+
+
 def test_device_seed_and_extension_matches_oracle(gpu_pair):
     import ctypes as C
     rnd = random.Random(4)

@@ -323,3 +323,90 @@ def test_bit_vector_lcs_and_edit_distance_equal_the_oracle_alignments():
         exp_e = -L.orc_global_alignment(a.encode(), b.encode(), 0, -1, -1, 0, 0, 0, 0)
         assert _lcs_bitpar(a, b) == exp_l and _lcs_bitpar(b, a) == exp_l, (len(a), len(b))
         assert _edit_bitpar(a, b) == exp_e and _edit_bitpar(b, a) == exp_e, (len(a), len(b))
+
+
+def _lcs_blocks(a, b, B):
+    """wave_lcs_bitpar's block form with blocks of B columns: block after block over all rows, one carry bit per row
+    handed from a block to the next (the carry out of the block's top bit)."""
+    m, carry, z = len(a), [0] * len(b), 0
+    for c0 in range(0, m, B):
+        mb = min(B, m - c0)
+        full = (1 << B) - 1
+        pm = {c: 0 for c in "ACGTN"}
+        for i in range(mb):
+            pm[a[c0 + i]] |= 1 << i
+        V = full
+        last = c0 + B >= m
+        for j, ch in enumerate(b):
+            Mm = pm[ch]
+            S = V + (V & Mm) + carry[j]
+            if not last:
+                carry[j] = S >> B
+            S &= full
+            V = S | (V & ~Mm & full)
+        z += sum(1 - ((V >> i) & 1) for i in range(mb))
+    return z
+
+
+def _edit_blocks(a, b, B):
+    """wave_edit_bitpar's block form (Myers' block formulation): the horizontal delta of a block's last row, +1 / 0 / -1 per
+    consumed base, enters the next block's first row; a -1 entering acts like a match in that row."""
+    m = len(a)
+    hp, hm = [1] * len(b), [0] * len(b)      # the border: +1 per column in row 0
+    score = m
+    for c0 in range(0, m, B):
+        mb = min(B, m - c0)
+        full = (1 << B) - 1
+        pm = {c: 0 for c in "ACGTN"}
+        for i in range(mb):
+            pm[a[c0 + i]] |= 1 << i
+        last = c0 + B >= m
+        top = (m - 1 - c0) if last else (B - 1)
+        Pv, Mv = full, 0
+        for j, ch in enumerate(b):
+            Eq = pm[ch]
+            Xv = Eq | Mv
+            Eqx = Eq | (1 if hm[j] else 0)
+            Xh = ((((Eqx & Pv) + Pv) & full) ^ Pv) | Eqx
+            Ph = Mv | (~(Xh | Pv) & full)
+            Mh = Pv & Xh
+            up, dn = (Ph >> top) & 1, (Mh >> top) & 1
+            Ph = ((Ph << 1) | hp[j]) & full
+            Mh = ((Mh << 1) | hm[j]) & full
+            if last:
+                score += up - dn
+            else:
+                hp[j], hm[j] = up, dn
+            Pv = Mh | (~(Xv | Ph) & full)
+            Mv = Ph & Xv
+    return score
+
+
+def test_bit_vector_block_hand_over_is_exact():
+    """Sequences beyond one 4096-column block: the block forms (blocks of 4, 7 and 64 columns here, so that every case of
+    the hand-over occurs many times) against the oracle's alignments, both argument orders."""
+    rnd = random.Random(78)
+    L = O.lib()
+    for it in range(120):
+        n = rnd.choice([1, 3, 4, 5, 8, 9, 29, 64, 65, 130, 200])
+        a = [rnd.choice("ACGTN" if rnd.random() < 0.1 else "ACGT") for _ in range(n)]
+        if rnd.random() < 0.7:
+            b = []
+            for ch in a:
+                x = rnd.random()
+                if x < 0.07:
+                    b.append(rnd.choice("ACGT"))
+                elif x < 0.14:
+                    b.append(ch)
+                    b.append(rnd.choice("ACGT"))
+                elif x >= 0.21:
+                    b.append(ch)
+            b = b or ["A"]
+        else:
+            b = [rnd.choice("ACGT") for _ in range(rnd.choice([1, 7, 64, 150]))]
+        a, b = "".join(a), "".join(b)
+        exp_l = L.orc_global_alignment(a.encode(), b.encode(), 1, 0, 0, 0, 0, 0, 0)
+        exp_e = -L.orc_global_alignment(a.encode(), b.encode(), 0, -1, -1, 0, 0, 0, 0)
+        for B in (4, 7, 64):
+            assert _lcs_blocks(a, b, B) == exp_l and _lcs_blocks(b, a, B) == exp_l, (len(a), len(b), B)
+            assert _edit_blocks(a, b, B) == exp_e and _edit_blocks(b, a, B) == exp_e, (len(a), len(b), B)
