@@ -787,6 +787,8 @@ TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
 // ------------------------------------------------------------------ anchors (Explorer.cpp:413-543)
 // side 0: anchorLEFTHandSide (walks the LEFT region leftwards from its end, degree towards RIGHT)
 // side 1: anchorRIGHTHandSide (walks the RIGHT region rightwards from its start, degree towards LEFT)
+TALC_DN void sort_anchors_long(AnchorRec* anc, int n, double cc) { gnu_sort(anc, n, LessAnchor{cc}); }
+
 TALC_DN void build_anchors(int side) {
   PROF_DECL;
   PROF_BEGIN();
@@ -917,7 +919,13 @@ TALC_DN void build_anchors(int side) {
     }
   }
   WSYNC();
-  if (l == 0 && nAnc > 1) gnu_sort(anc, (int)nAnc, LessAnchor{X.lambda / P.ERR});
+  // std::sort of a list of at most 16 elements IS its final insertion sort (the introsort loop does nothing below 17):
+  // nearly every anchor list is that short, and the full routine — a real call — keeps its stack arrays and registers
+  // out of this function
+  if (l == 0 && nAnc > 1) {
+    if (nAnc <= 16) gs_insertion_sort(anc, 0, (int)nAnc, LessAnchor{X.lambda / P.ERR});
+    else sort_anchors_long(anc, (int)nAnc, X.lambda / P.ERR);
+  }
   WSYNC();
   if (side == 0) X.nAncL = (int)nAnc; else X.nAncR = (int)nAnc;
   PROF_END(PF_ANCHORS);
