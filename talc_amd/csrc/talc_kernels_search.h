@@ -66,8 +66,14 @@ struct SearchLimits {   // (the part the search itself consults: a copy lives in
 struct SearchCaps : SearchLimits {
   uint64_t slotBytes;
   uint64_t o_setA, o_setB, o_seqPool, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
-      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak;
+      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak, o_wideBloom;
 };
+
+// The cycle filter of a LONG search (a gap of several kb: a Trail of thousands of k-mers saturates the 8192 bits the wave
+// has in LDS, and every false alarm costs an exact window search over the whole path): up to 2^20 bits per wave in HBM,
+// sized per search at ~32 bits per possible k-mer, read and written by agent-scope atomics (the L2 is their coherence point).
+#define WIDE_BLOOM_WORDS 16384
+#define WIDE_BLOOM_MIN_PATH 1500   /* Trails that may grow beyond this many bases use it */
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
@@ -137,6 +143,7 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   c.o_wOff = take((uint64_t)c.regCap * 4);
   c.o_wLen = take((uint64_t)c.regCap * 4);
   c.o_weak = take(c.weakPool);
+  c.o_wideBloom = take((uint64_t)WIDE_BLOOM_WORDS * 8);
   c.slotBytes = align_up(o, 256);
   return c;
 }
@@ -526,6 +533,8 @@ struct Wv {
   AnchorRec *ancL, *ancR; uint32_t* ancPos;
   FullMeta* fullMeta;
   int *dpG;   // 3 x dpCap ints in HBM
+  unsigned long long* wideBloom;   // WIDE_BLOOM_WORDS words in HBM
+  uint32_t wideMask;               // words - 1 of the current search's wide filter; 0: the LDS filter is in use
   double* gScores; double* gDists; ValIdx* gVal; Rank4* gRank; uint32_t* gKept;
   uint32_t *regS, *regE, *wOff, *wLen;
   // explorer state (Explorer.hpp:151-174)
@@ -774,8 +783,25 @@ TALC_D uint64_t bloom_hash(uint64_t kmer, uint64_t nmask) {
 TALC_D int bloom_word(uint64_t h) { return (int)(h >> 57); }
 TALC_D unsigned long long bloom_mask(uint64_t h) { return (1ull << ((h >> 51) & 63)) | (1ull << ((h >> 45) & 63)); }
 static_assert(BLOOM_WORDS == 128, "bloom_word takes 7 hash bits");
+// the wide filter's word and bits from the same hash (upper 32 bits `hv`): 14 + 6 + 6 bits below the LDS filter's 7
+TALC_D uint32_t wide_word(uint32_t hv, uint32_t mask) { return (hv >> 18) & mask; }
+TALC_D unsigned long long wide_bits(uint32_t hv) { return (1ull << ((hv >> 12) & 63u)) | (1ull << ((hv >> 6) & 63u)); }
+TALC_D unsigned long long wide_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+TALC_D void wide_or(unsigned long long* p, unsigned long long m) {
+  __hip_atomic_fetch_or(p, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
   const uint64_t h = bloom_hash(kmer, nmask);
+  const uint32_t wm = (uint32_t)uni((int)X.wideMask);
+  if (wm != 0u) {
+    const uint32_t hv = (uint32_t)(h >> 32);
+    unsigned long long* w = X.wideBloom + wide_word(hv, wm);
+    const unsigned long long m = wide_bits(hv), v = wide_load(w);
+    if (lane_id() == 0) wide_or(w, m);
+    return (v & m) == m;
+  }
   const int w = bloom_word(h);
   const unsigned long long m = bloom_mask(h), v = g_bloom[w];
   const bool maybe = (v & m) == m;
@@ -1758,7 +1784,8 @@ TALC_D uint32_t dpp_row_shr(uint32_t v, uint32_t old) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x110 + P, 0xF, 0xF, false);
 }
 
-template <bool dirRight>
+// WIDEF: the search's cycle filter is the wide one in HBM (an instance of its own: the common form's loop stays as it is)
+template <bool dirRight, bool WIDEF>
 TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXLENGTH_, bool edge_) {
   PROF_DECL; PROF_DECL2;
   PROF_BEGIN2();
@@ -1772,6 +1799,8 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   const uint32_t seqCap = (uint32_t)uni((int)X.C.seqCap), PMAX = (uint32_t)uni((int)PATH_MAXLENGTH_);
   const uint64_t cap = uni64(X.T.capacity);
   const uint32_t TALC_AS1* wtab = (const uint32_t TALC_AS1*)uni_ptr(dirRight ? X.T.walkRight : X.T.walkLeft);
+  const uint32_t wideMask = WIDEF ? (uint32_t)uni((int)X.wideMask) : 0u;
+  unsigned long long* const wideBloom = WIDEF ? (unsigned long long*)uni_ptr(X.wideBloom) : nullptr;
   const uint64_t kmask = (1ULL << (2 * K)) - 1, m1 = (1ULL << (2 * (K - 1))) - 1;
   uint64_t kmer = uni64(r0.kmer);
   uint32_t cnt = (uint32_t)uni((int)r0.cnt);
@@ -1880,8 +1909,11 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     static_assert(TALC_WALK_LEVELS == 14, "the lane roles above are written for 14 levels in a 16-lane row");
     // aim / cycle query against the search's filter (init_first_trail entered the aims)
     const int bwi = (int)(hv >> 25);     // bloom_word / bloom_mask on the upper half of the hash
-    const unsigned long long bm = (1ull << ((hv >> 19) & 63u)) | (1ull << ((hv >> 13) & 63u));
-    const unsigned long long bv = g_bloom[bwi];
+    unsigned long long bm = (1ull << ((hv >> 19) & 63u)) | (1ull << ((hv >> 13) & 63u));
+    unsigned long long bv;
+    unsigned long long* const wideW = WIDEF ? wideBloom + wide_word(hv, wideMask) : nullptr;
+    if (WIDEF) { bm = wide_bits(hv); bv = (l < TALC_WALK_LEVELS) ? wide_load(wideW) : 0ull; }   // a long search's filter (HBM)
+    else bv = g_bloom[bwi];
     const unsigned long long hitMask = ballot64(((bv & bm) == bm) || dup) | (1ull << TALC_WALK_LEVELS);
     const int hitLevel = __builtin_ctzll(hitMask);
     // a filter hit on a level that could otherwise be taken: if its k-mer is an aim, that step is a plain step that
@@ -1898,7 +1930,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     if (nTake == 0) break;
     // ---- commit nTake steps
     if (l < nTake) {
-      atomicOr(&g_bloom[bwi], bm);
+      if (WIDEF) wide_or(wideW, bm); else atomicOr(&g_bloom[bwi], bm);
       recN[done - flushed + l] = top;
       seq[len0 + done + l] = (uint8_t)which;
     }
@@ -1951,11 +1983,19 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   return done;
 }
 
+// (the long searches' instances: a function of their own, so that the common one's code stays together)
+TALC_DN int fast_forward_wide(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
+  return uni((int)X.dirRight) ? fast_forward_walk<true, true>(len, stepCounter, PATH_MAXLENGTH, edge)
+                              : fast_forward_walk<false, true>(len, stepCounter, PATH_MAXLENGTH, edge);
+}
 TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
   // the walk tables encode "count >= MIN_COUNT" for MIN_COUNT below 2^14 only (talc_common.h)
   if (uni((int)(X.T.walkRight != nullptr && X.P.MIN_COUNT <= kWalkNextMask)) != 0)
-    return uni((int)X.dirRight) ? fast_forward_walk<true>(len, stepCounter, PATH_MAXLENGTH, edge)
-                                : fast_forward_walk<false>(len, stepCounter, PATH_MAXLENGTH, edge);
+  {
+    if (uni((int)X.wideMask) != 0) [[clang::musttail]] return fast_forward_wide(len, stepCounter, PATH_MAXLENGTH, edge);
+    return uni((int)X.dirRight) ? fast_forward_walk<true, false>(len, stepCounter, PATH_MAXLENGTH, edge)
+                                : fast_forward_walk<false, false>(len, stepCounter, PATH_MAXLENGTH, edge);
+  }
   return uni((int)X.dirRight) ? fast_forward_dir<true>(len, stepCounter, PATH_MAXLENGTH, edge)
                               : fast_forward_dir<false>(len, stepCounter, PATH_MAXLENGTH, edge);
 }
@@ -1963,11 +2003,22 @@ TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
 // A bridge's search also enters its aims (the target anchors, Explorer.cpp:920) in the search's filter: the
 // fast-forward loop then needs no aim comparison of its own (a step onto an aim is a filter hit).
-TALC_D void init_first_trail(const AnchorRec& a, bool withAims) {
+TALC_D void init_first_trail(const AnchorRec& a, bool withAims, uint32_t pathMax) {
   const int K = (int)X.P.K;
   pool_reset();
   const uint32_t b0 = (uint32_t)pool_alloc();
   wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
+  // the search's cycle filter: the wave's 8192 bits of LDS, or — for a Trail that may grow to thousands of k-mers, and
+  // when the walk-table form of the fast-forward (the one that can read it) is in use — the wide one in HBM
+  uint32_t wm = 0;
+  if (pathMax > (uint32_t)WIDE_BLOOM_MIN_PATH && X.wideBloom != nullptr && X.T.walkRight != nullptr && X.P.MIN_COUNT <= kWalkNextMask) {
+    uint32_t words = 1024;
+    while (words < (uint32_t)WIDE_BLOOM_WORDS && words < pathMax / 2) words <<= 1;
+    wm = words - 1;
+    for (uint32_t i = (uint32_t)lane_id(); i < words; i += 64) X.wideBloom[i] = 0ull;
+    WSYNC();
+  }
+  X.wideMask = (uint32_t)uni((int)wm);
   g_bloom[lane_id()] = 0ull; g_bloom[lane_id() + 64] = 0ull;
   LSYNC();
   if (withAims) {
@@ -1978,7 +2029,8 @@ TALC_D void init_first_trail(const AnchorRec& a, bool withAims) {
       const uint64_t tk = ai < AIMS_LDS ? g_aimK[ai] : aims[ai].kmer, tn = ai < AIMS_LDS ? g_aimN[ai] : aims[ai].nmask;
       if (tn != 0ull) continue;   // a fast-forwarded tip never holds an N
       const uint64_t h = bloom_hash(tk, 0ull);
-      atomicOr(&g_bloom[bloom_word(h)], bloom_mask(h));
+      if (wm != 0u) wide_or(X.wideBloom + wide_word((uint32_t)(h >> 32), wm), wide_bits((uint32_t)(h >> 32)));
+      else atomicOr(&g_bloom[bloom_word(h)], bloom_mask(h));
     }
     LSYNC();
   }
@@ -2052,7 +2104,7 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
     if (!pool_shape(PATH_MAXLENGTH)) return false;
-    PROF_BEGIN2(); init_first_trail(a, true); PROF_END2(PF_INITTR);
+    PROF_BEGIN2(); init_first_trail(a, true, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
     const uint32_t maxInner = (uint32_t)uni((int)P.MAX_INNER_PATHS);
@@ -2182,7 +2234,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
     if (!pool_shape(PATH_MAXLENGTH)) return false;
-    PROF_BEGIN2(); init_first_trail(a, false); PROF_END2(PF_INITTR);
+    PROF_BEGIN2(); init_first_trail(a, false, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
     while ((int)(nCur > 0) & (int)((uint32_t)nCur <= maxInner) & (int)((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH) & (int)(uni((int)X.overflow) == 0)) {
@@ -2266,6 +2318,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.fullMeta = (FullMeta*)(slot + C.o_fullMeta); X.fullPool = slot + C.o_fullPoolB;
   X.edgeLong = slot + C.o_edgeLong; X.edgeShort = slot + C.o_edgeShort; X.edgeTmp = slot + C.o_edgeTmp;
   X.dpG = (int*)(slot + C.o_dp);
+  X.wideBloom = (unsigned long long*)(slot + C.o_wideBloom); X.wideMask = 0;
   {
     uint8_t* g = slot + C.o_gard;
     X.gScores = (double*)g; g += 8ull * (TCAP + 64);
