@@ -73,7 +73,9 @@ struct SearchCaps : SearchLimits {
 // has in LDS, and every false alarm costs an exact window search over the whole path): up to 2^20 bits per wave in HBM,
 // sized per search at ~32 bits per possible k-mer, read and written by agent-scope atomics (the L2 is their coherence point).
 #define WIDE_BLOOM_WORDS 16384
-#define WIDE_BLOOM_MIN_PATH 1500   /* Trails that may grow beyond this many bases use it */
+#ifndef WIDE_BLOOM_MIN_PATH
+#define WIDE_BLOOM_MIN_PATH 600   /* Trails that may grow beyond this many bases use it (config 5: search 122 / 113 / 107 / 104 / 103 / 104 ms at 2500 / 1500 / 1000 / 700 / 450 / 300) */
+#endif
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
