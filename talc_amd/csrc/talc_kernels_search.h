@@ -1516,6 +1516,13 @@ TALC_DN int score_edges(int ib_, int n_, int len_, int& xdrop_) {
   const int l = lane_id();
   const int ib = uni(ib_);
   const int xdrop = uni(xdrop_) + 2;
+  if (n == 1) {
+    // the common case, one live Trail: the same outcome without the survivor flags' trip through memory and its barriers
+    const bool ok = uni((int)trail_seed_and_extend(ib, 0, len, xdrop)) != 0;
+    xdrop_ = ok ? (int)((double)uni(tr_get(ib, 0).score) * (-1)) : 0;
+    if (!ok) { record_edge(ib, 0, len); pool_free((uint32_t)uni((int)tr_buf(ib, 0))); return 0; }
+    return 1;
+  }
   int new_xdrop = 0;
   int nSel = 0;
   // trash paths are only needed when nobody survives: remember them by flag in gKept
