@@ -66,12 +66,21 @@ struct SearchLimits {   // (the part the search itself consults: a copy lives in
 struct SearchCaps : SearchLimits {
   uint64_t slotBytes;
   uint64_t o_setA, o_setB, o_seqPool, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
-      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak, o_wideBloom;
+      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak, o_wideBloom, o_rowPool;
 };
 
 // The cycle filter of a LONG search (a gap of several kb: a Trail of thousands of k-mers saturates the 8192 bits the wave
 // has in LDS, and every false alarm costs an exact window search over the whole path): up to 2^20 bits per wave in HBM,
 // sized per search at ~32 bits per possible k-mer, read and written by agent-scope atomics (the L2 is their coherence point).
+// scoreBridges' alignments continued row by row (wave_nw_rows): the last matrix row of every Trail, over the whole
+// reference.  One arena per wave, cut per search into records of refLen + 2 ints (as many as fit, at most one per Trail
+// buffer; a Trail whose buffer has no record, and every reference beyond ROW_MAX_REF bases, is aligned from scratch).
+// A record's word 0 (column 0 of the matrix is zero by definition) says how many rows (= Trail bases) the record covers
+// and in which search of the wave, its last word in which launch (DevParams::launchStamp): nothing is reset per search,
+// and neither an earlier launch's records nor — the slots move when the batch's longest read changes — another wave's
+// are ever taken for this search's.
+#define ROW_ARENA_INTS (448 * 1024)
+#define ROW_MAX_REF 2047
 #define WIDE_BLOOM_WORDS 16384
 #ifndef WIDE_BLOOM_MIN_PATH
 #define WIDE_BLOOM_MIN_PATH 600   /* Trails that may grow beyond this many bases use it (config 5: search 122 / 113 / 107 / 104 / 103 / 104 ms at 2500 / 1500 / 1000 / 700 / 450 / 300) */
@@ -146,6 +155,7 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   c.o_wLen = take((uint64_t)c.regCap * 4);
   c.o_weak = take(c.weakPool);
   c.o_wideBloom = take((uint64_t)WIDE_BLOOM_WORDS * 8);
+  c.o_rowPool = take((uint64_t)ROW_ARENA_INTS * 4);
   c.slotBytes = align_up(o, 256);
   return c;
 }
@@ -536,6 +546,9 @@ struct Wv {
   FullMeta* fullMeta;
   int *dpG;   // 3 x dpCap ints in HBM
   unsigned long long* wideBloom;   // WIDE_BLOOM_WORDS words in HBM
+  int* rowPool;                    // ROW_ARENA_INTS ints in HBM (nullptr: every scoring aligns from scratch)
+  uint32_t searchNo;               // number of the current search of this wave (stamps the kept rows)
+  uint32_t rowStride, rowAvail;    // the current search's records: ints per record, records (0: none)
   uint32_t wideMask;               // words - 1 of the current search's wide filter; 0: the LDS filter is in use
   double* gScores; double* gDists; ValIdx* gVal; Rank4* gRank; uint32_t* gKept;
   uint32_t *regS, *regE, *wOff, *wLen;
@@ -603,7 +616,17 @@ TALC_DN int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int mat
   if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
   unsigned long long ncells = 0;
   if (la <= 64 * NW_REG_NB) {
-    const int r = wave_nw_reg<NW_REG_NB>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
+    // an instance per block width (columns per lane): the sweep's inner loop is unrolled over the block, and a 12-wide
+    // instance spends 12 predicated cell updates per step on a 130-base sequence that has 3 per lane
+    const int B = (la + 63) >> 6;
+    int r;
+    if (B <= 1) r = wave_nw_reg<1>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
+    else if (B <= 2) r = wave_nw_reg<2>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
+    else if (B <= 3) r = wave_nw_reg<3>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
+    else if (B <= 4) r = wave_nw_reg<4>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
+    else if (B <= 6) r = wave_nw_reg<6>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
+    else if (B <= 8) r = wave_nw_reg<8>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
+    else r = wave_nw_reg<NW_REG_NB>(a, la, b, lb, match, mismatch, gap, freeBegin, ncells);
     X.cells += ncells;
     return r;
   }
@@ -745,6 +768,42 @@ TALC_D int pool_alloc() {
 TALC_D void pool_free(uint32_t id) {
 #pragma unroll
   for (int w = 0; w < NBUF / 64; ++w) if ((int)(id >> 6) == w) X.freeMask[w] |= (1ull << (id & 63));
+}
+// the records of the search that starts now (its reference is complete): stride, count, a new search number
+TALC_D void rows_shape() {
+  const uint32_t n = (uint32_t)uni((int)X.refLen);
+  uint32_t stride = 0, avail = 0;
+  const uint32_t sn = (uint32_t)uni((int)X.searchNo) + 1u;
+  if (X.rowPool != nullptr && n <= (uint32_t)ROW_MAX_REF && sn < 0xFFFF0u) {   // (a wave's millionth search of a launch goes without)
+    stride = (n + 2u + 3u) & ~3u;
+    avail = min((uint32_t)NBUF, (uint32_t)ROW_ARENA_INTS / stride);
+  }
+  X.rowStride = stride; X.rowAvail = avail;
+  X.searchNo = min(sn, 0xFFFF0u);
+}
+TALC_D int* row_of(uint32_t buf) { return X.rowPool + (uint64_t)buf * X.rowStride; }
+// rows of the alignment matrix the record of buffer `buf` covers in the current search (0: none)
+TALC_D uint32_t row_covered(uint32_t buf) {
+  const int* rec = row_of(buf);
+  const uint32_t lo = (uint32_t)uni(rec[0]), hi = (uint32_t)uni(rec[(uint32_t)uni((int)X.refLen) + 1u]);
+  return (hi == (uint32_t)uni((int)X.P.launchStamp) && (lo >> 12) == (uint32_t)uni((int)X.searchNo)) ? (lo & 0xFFFu) : 0u;
+}
+TALC_D void row_set_covered(uint32_t buf, uint32_t covered) {
+  if (lane_id() == 0) {
+    int* rec = row_of(buf);
+    rec[0] = (int)((X.searchNo << 12) | (covered & 0xFFFu));
+    rec[X.refLen + 1u] = (int)X.P.launchStamp;
+  }
+}
+// the record of the Trail in buffer `src` goes with a copy of that Trail into buffer `dst`
+TALC_DN void row_copy(uint32_t dst_, uint32_t src_) {
+  const uint32_t dst = (uint32_t)uni((int)dst_), src = (uint32_t)uni((int)src_);
+  const uint32_t avail = (uint32_t)uni((int)X.rowAvail);
+  if (dst >= avail) return;
+  WSYNC();   // (the record and its stamp were left by other lanes)
+  const uint32_t covered = (src < avail) ? row_covered(src) : 0u;
+  if (covered) wave_copy((uint8_t*)row_of(dst), (const uint8_t*)row_of(src), (uint32_t)uni((int)X.rowStride) * 4u);
+  else row_set_covered(dst, 0u);
 }
 // slots >= HOT live in HBM; these are real calls so that the optimiser never merges an LDS and an
 // HBM access into one access through a pointer of mixed provenance (which would become flat_*)
@@ -1319,6 +1378,7 @@ TALC_D void make_child(int t, int c, int b, int len, uint32_t count, double dist
     cbuf = (uint32_t)pool_alloc();
     WSYNC();   // bases appended by lane 0 in earlier steps must be visible to the copying lanes
     wave_copy(X.seqPool + (uint64_t)cbuf * X.C.seqCap, X.seqPool + (uint64_t)p.buf * X.C.seqCap, (uint32_t)len);
+    if (uni((int)X.location) == LOC_INNER) row_copy(cbuf, p.buf);
   }
   if (X.dirRight) { km2 = ((p.kmer << 2) | (uint64_t)b) & kmask; nm2 = p.nmask >> 1; }
   else { km2 = ((uint64_t)b << (2 * (K - 1))) | (p.kmer >> 2); nm2 = (p.nmask << 1) & ((1ULL << K) - 1); }
@@ -1379,6 +1439,7 @@ TALC_DN int garden(int n, int len, bool& isComplex) {
     TrailRec r = tr_get(ib, (int)src);
     const uint32_t nb = (uint32_t)pool_alloc();
     wave_copy(X.seqPool + (uint64_t)nb * X.C.seqCap, X.seqPool + (uint64_t)r.buf * X.C.seqCap, (uint32_t)len);
+    if (uni((int)X.location) == LOC_INNER) row_copy(nb, r.buf);
     r.buf = nb;
     if (l == 0) tr_put(X.ia, i, r);
   }
@@ -1395,6 +1456,34 @@ TALC_D int last_successor(int tags) {
 }
 
 // Explorer::oneMoreStep (Explorer.cpp:546-612).  nCur trails of length len in the current set.
+// Trail::Overlapscore (Trail.cpp:145-173) of the Trail in buffer `buf` (m bases) against the first tlen bases of the
+// reference, from the row the Trail (or the Trail it was copied from) left at its last scoring
+TALC_DN int score_bridge_rows(uint32_t buf_, int tlen_, int m_) {
+  const uint32_t buf = (uint32_t)uni((int)buf_);
+  const int tlen = uni(tlen_), m = uni(m_);
+  const int n = (int)uni((int)X.refLen);
+  WSYNC();   // the row and its stamp may have arrived by a copy, the Trail's last bases by lane 0
+  int i0 = (int)row_covered(buf);
+  if (i0 > m) i0 = 0;   // (cannot happen: a Trail only grows)
+  int* row = row_of(buf);
+  const uint8_t* cand = X.seqPool + (uint64_t)buf * X.C.seqCap;
+  unsigned long long ncells = 0;
+  const int B = (n + 63) >> 6;
+  int sc;
+  if (B <= 2) sc = wave_nw_rows<2>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
+  else if (B <= 4) sc = wave_nw_rows<4>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
+  else if (B <= 6) sc = wave_nw_rows<6>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
+  else if (B <= 8) sc = wave_nw_rows<8>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
+  else if (B <= 12) sc = wave_nw_rows<12>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
+  else if (B <= 16) sc = wave_nw_rows<16>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
+  else if (B <= 24) sc = wave_nw_rows<24>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
+  else sc = wave_nw_rows<32>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
+  static_assert(ROW_MAX_REF <= 64 * 32 - 1, "the widest instance takes 32 columns per lane");
+  X.cells += ncells;
+  row_set_covered(buf, (uint32_t)m);
+  return sc;
+}
+
 TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   PROF_DECL;
   const DevParams& P = X.P;
@@ -1488,9 +1577,12 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
     const int tlen = (int)min(bound, X.refLen);
     PROF_BEGIN();
     WSYNC();
+    const uint32_t rowAvail = ((uint32_t)(len + 1) < 4096u) ? (uint32_t)uni((int)X.rowAvail) : 0u;
     for (int j = 0; j < nNew; ++j) {
       TrailRec r = tr_get(ib, j);
-      r.score = nw_score(X.ref, tlen, X.seqPool + (uint64_t)r.buf * X.C.seqCap, len + 1, 4, -3, -2, true);
+      const uint32_t rb = (uint32_t)uni((int)r.buf);
+      if (rb < rowAvail) r.score = score_bridge_rows(rb, tlen, len + 1);
+      else r.score = nw_score(X.ref, tlen, X.seqPool + (uint64_t)rb * X.C.seqCap, len + 1, 4, -3, -2, true);
       if (l == 0) tr_put(ib, j, r);
     }
     WSYNC();
@@ -2113,6 +2205,7 @@ TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t&
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
     if (!pool_shape(PATH_MAXLENGTH)) return false;
+    rows_shape();
     PROF_BEGIN2(); init_first_trail(a, true, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
@@ -2328,6 +2421,8 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.edgeLong = slot + C.o_edgeLong; X.edgeShort = slot + C.o_edgeShort; X.edgeTmp = slot + C.o_edgeTmp;
   X.dpG = (int*)(slot + C.o_dp);
   X.wideBloom = (unsigned long long*)(slot + C.o_wideBloom); X.wideMask = 0;
+  X.rowPool = (P.flags & 1u) ? nullptr : (int*)(slot + C.o_rowPool); X.rowStride = 0; X.rowAvail = 0;   // (flags bit 0: TALC_NO_ROWS)
+  X.searchNo = 16u;   // (stamps below 16 << 12 could be matrix values)
   {
     uint8_t* g = slot + C.o_gard;
     X.gScores = (double*)g; g += 8ull * (TCAP + 64);

@@ -326,6 +326,79 @@ TALC_D int wave_nw_reg(const uint8_t* __restrict__ H_, int n, const uint8_t* __r
   return lane_get(res, ln);
 }
 
+// ------------------------------------------------------------------ NW continued row by row (n <= 64*NB)
+// scoreBridges (Explorer.cpp:689-706) aligns every live Trail against the reference again every CHECK_INTERVAL steps,
+// from scratch (Trail::Overlapscore, Trail.cpp:145-173: free begin, end gaps charged).  The matrix cell (i, j) of such an
+// alignment depends on the first i bases of the Trail and the first j of the reference only — neither the Trail's later
+// bases nor the truncation of the reference change it — so a Trail that keeps the last row it has computed (over the
+// WHOLE reference) only needs the rows of its new bases: rows i0+1 .. m of the free-begin matrix of V (rows) against H
+// (columns), continued from row i0 in rowIO[1..n] (i0 == 0: row 0 is all zero and rowIO is not read); leaves row m
+// there and returns D[m][outCol] = the score of V[0, m) against H[0, outCol).  Same sweep as wave_nw_reg.
+template <int NB>
+TALC_D int wave_nw_rows(const uint8_t* __restrict__ H_, int n, const uint8_t* __restrict__ V_, int i0, int m, int match, int mismatch,
+                        int gap, int* rowIO_, int outCol, unsigned long long& cells) {
+  gcu8 H = (gcu8)uni_ptr(H_); gcu8 V = (gcu8)uni_ptr(V_);
+  int TALC_AS1* rowIO = (int TALC_AS1*)uni_ptr(rowIO_);   // [0] belongs to the caller (column 0 is zero by definition)
+  const int l = lane_id();
+  n = uni(n); m = uni(m); i0 = uni(i0); outCol = uni(outCol); match = uni(match); mismatch = uni(mismatch); gap = uni(gap);
+  const int rows = m - i0;
+  cells += (unsigned long long)n * (unsigned long long)max(rows, 0);
+  const int B = (n + 63) >> 6;
+  const int nl = (n + B - 1) / B;
+  const int j0 = l * B + 1;
+  const int nOwn = max(0, min(B, n - j0 + 1));
+  constexpr int NP = (NB + 3) / 4;
+  unsigned hp[NP];   // the lane's column bases, four per register
+  int r[NB];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) hp[q] = 0xFFFFFFFFu;
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) {
+    const int j = j0 + jj;
+    if (jj < nOwn) hp[jj >> 2] = (hp[jj >> 2] & ~(0xFFu << (8 * (jj & 3)))) | ((unsigned)H[j - 1] << (8 * (jj & 3)));
+    r[jj] = (jj < nOwn && i0 > 0) ? rowIO[j] : 0;
+  }
+  int lastOut = 0;   // row i0 at the last own column
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) if (jj == nOwn - 1) lastOut = r[jj];
+  int prevLastOut = lastOut;
+  const int T = rows + nl - 1;
+  int vcur = (l == 0 && rows > 0) ? (int)V[i0] : 0;
+  for (int t = 1; t <= T; ++t) {
+    int vnext = 0;
+    { const int idx = t - l; if (idx >= 0 && idx < rows) vnext = (int)V[i0 + idx]; }
+    const int nbLast = lane_shr1(lastOut);
+    const int nbPrev = lane_shr1(prevLastOut);
+    const int i = t - l;
+    if (l < nl && i >= 1 && i <= rows) {
+      int left = (l == 0) ? 0 : nbLast, diag = (l == 0) ? 0 : nbPrev;   // (column 0 is free: all zero)
+      int v = left;
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) {
+        if (jj < nOwn) {
+          const int up = r[jj];
+          const int hb = (int)((hp[jj >> 2] >> (8 * (jj & 3))) & 0xFFu);
+          const int d = diag + ((hb == vcur) ? match : mismatch);
+          v = max(d, max(up + gap, left + gap));
+          r[jj] = v;
+          diag = up;
+          left = v;
+        }
+      }
+      prevLastOut = diag;
+      lastOut = v;
+    }
+    vcur = vnext;
+  }
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) if (jj < nOwn) rowIO[j0 + jj] = r[jj];
+  const int ln = (outCol - 1) / B, tj = (outCol - 1) - ln * B;
+  int res = 0;
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) if (jj == tj) res = r[jj];
+  return lane_get(res, ln);
+}
+
 // ------------------------------------------------------------------ fused edit distance + LCS (n <= 64*NB)
 // The reference always scores a candidate twice against the same reference: globalAlignment with
 // Score(0,-1,-1) (= -edit distance, Trajectory.cpp:413 / Trail.cpp:422) and localAlignment with

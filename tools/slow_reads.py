@@ -1,6 +1,6 @@
 """Development tool: category profile of a handful of reads of a bench workload (the profile build of the library).
     TALC_LIB=talc_amd/_build/libtalc_hip_prof.so TALC_PROF_PRINT=1 python tools/slow_reads.py 5 49157 87728 ...
-prints k_search's category profile for a batch that holds only those reads of BASELINE config <n>, and their lengths,
+prints k_search's category profile for a batch that holds only those reads of BASELINE config <n> (or `paralog`), and their lengths,
 statuses and the number of regions the structure step found."""
 import os
 import sys
@@ -13,11 +13,14 @@ from talc_amd.synth import Synth
 
 
 def main():
-    cfg = int(sys.argv[1])
     ids = [int(x) for x in sys.argv[2:]]
-    w = dict(B.CONFIGS[cfg])
-    synth = Synth(target_kmers=w["kmers"], k=w["k"], seed=0, mixed_lengths=int(w["mixed"]))
-    params = T.default_params(k=w["k"], use_junctions=int(w["junctions"]))
+    if sys.argv[1] == "paralog":     # bench.py's paralog side workload
+        synth = Synth(target_kmers=2_000_000, k=25, seed=77, paralog_frac=0.6, paralog_div=0.05)
+        params = T.default_params(k=25)
+    else:
+        w = dict(B.CONFIGS[int(sys.argv[1])])
+        synth = Synth(target_kmers=w["kmers"], k=w["k"], seed=0, mixed_lengths=int(w["mixed"]))
+        params = T.default_params(k=w["k"], use_junctions=int(w["junctions"]))
     keys, counts = synth.dump_arrays()
     table = T.Table.from_arrays(keys, counts, params, device=0)
     table.decolour_repeats()
