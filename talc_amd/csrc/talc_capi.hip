@@ -579,7 +579,6 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   d.MAX_IN_COUNT = p->max_in_count; d.MAX_BORDER_PATHS = p->max_nb_border_paths; d.MAX_INNER_PATHS = p->max_nb_inner_paths;
   d.CHECK_INTERVAL = p->check_interval; d.FAILURE_RATE = p->allowed_failure_rate;
   d.MAX_BORDER_FAILURES = p->max_nb_border_failures; d.MAX_BORDER_LEN = p->max_border_length;
-  d.flags = getenv("TALC_NO_ROWS") ? 1u : 0u;   // (diagnostic: scoreBridges aligns every Trail from scratch)
   d.costEdgeLin = 2800; d.costEdgeQuad = 135;
   if (const char* e = getenv("TALC_COST_LIN")) d.costEdgeLin = (uint32_t)strtoul(e, nullptr, 10);     // (tuning runs)
   if (const char* e = getenv("TALC_COST_QUAD")) d.costEdgeQuad = (uint32_t)strtoul(e, nullptr, 10);

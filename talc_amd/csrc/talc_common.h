@@ -213,8 +213,6 @@ struct DevParams {
   uint32_t MAX_BORDER_LEN;
   // work estimate of an edge of h bases, in wave-cycles (only the order of the work queue depends on it; k_structure)
   uint32_t costEdgeLin, costEdgeQuad;
-  uint32_t flags;   // bit 0: no kept alignment rows (diagnostic)
-  uint32_t launchStamp;   // a number no other k_search launch of this process carries (stamps the kept alignment rows)
 };
 
 }  // namespace talc

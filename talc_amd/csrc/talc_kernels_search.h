@@ -76,10 +76,12 @@ struct SearchCaps : SearchLimits {
 // reference.  One arena per wave, cut per search into records of refLen + 2 ints (as many as fit, at most one per Trail
 // buffer; a Trail whose buffer has no record, and every reference beyond ROW_MAX_REF bases, is aligned from scratch).
 // A record's word 0 (column 0 of the matrix is zero by definition) says how many rows (= Trail bases) the record covers
-// and in which search of the wave, its last word in which launch (DevParams::launchStamp): nothing is reset per search,
+// and in which search of the wave, its last word in which launch (k_search's launchStamp): nothing is reset per search,
 // and neither an earlier launch's records nor — the slots move when the batch's longest read changes — another wave's
 // are ever taken for this search's.
+#ifndef ROW_ARENA_INTS
 #define ROW_ARENA_INTS (448 * 1024)
+#endif
 #define ROW_MAX_REF 2047
 #define WIDE_BLOOM_WORDS 16384
 #ifndef WIDE_BLOOM_MIN_PATH
@@ -545,11 +547,6 @@ struct Wv {
   AnchorRec *ancL, *ancR; uint32_t* ancPos;
   FullMeta* fullMeta;
   int *dpG;   // 3 x dpCap ints in HBM
-  unsigned long long* wideBloom;   // WIDE_BLOOM_WORDS words in HBM
-  int* rowPool;                    // ROW_ARENA_INTS ints in HBM (nullptr: every scoring aligns from scratch)
-  uint32_t searchNo;               // number of the current search of this wave (stamps the kept rows)
-  uint32_t rowStride, rowAvail;    // the current search's records: ints per record, records (0: none)
-  uint32_t wideMask;               // words - 1 of the current search's wide filter; 0: the LDS filter is in use
   double* gScores; double* gDists; ValIdx* gVal; Rank4* gRank; uint32_t* gKept;
   uint32_t *regS, *regE, *wOff, *wLen;
   // explorer state (Explorer.hpp:151-174)
@@ -567,6 +564,13 @@ struct Wv {
   unsigned long long cells, steps;
   uint32_t overflow;
   TraceBuf trace; bool tracing;
+  // (later additions go here, at the end: the offsets of the fields above are what the hot code's LDS addressing sees)
+  unsigned long long* wideBloom;   // WIDE_BLOOM_WORDS words in HBM
+  int* rowPool;                    // ROW_ARENA_INTS ints in HBM (nullptr: every scoring aligns from scratch)
+  uint32_t searchNo;               // number of the current search of this wave (stamps the kept rows)
+  uint32_t rowStride, rowAvail;    // the current search's records: ints per record, records (0: none)
+  uint32_t wideMask;               // words - 1 of the current search's wide filter; 0: the LDS filter is in use
+  uint32_t launchStamp;            // a number no other k_search launch of this process carries (stamps the kept rows)
 };
 
 enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
@@ -786,13 +790,13 @@ TALC_D int* row_of(uint32_t buf) { return X.rowPool + (uint64_t)buf * X.rowStrid
 TALC_D uint32_t row_covered(uint32_t buf) {
   const int* rec = row_of(buf);
   const uint32_t lo = (uint32_t)uni(rec[0]), hi = (uint32_t)uni(rec[(uint32_t)uni((int)X.refLen) + 1u]);
-  return (hi == (uint32_t)uni((int)X.P.launchStamp) && (lo >> 12) == (uint32_t)uni((int)X.searchNo)) ? (lo & 0xFFFu) : 0u;
+  return (hi == (uint32_t)uni((int)X.launchStamp) && (lo >> 12) == (uint32_t)uni((int)X.searchNo)) ? (lo & 0xFFFu) : 0u;
 }
 TALC_D void row_set_covered(uint32_t buf, uint32_t covered) {
   if (lane_id() == 0) {
     int* rec = row_of(buf);
     rec[0] = (int)((X.searchNo << 12) | (covered & 0xFFFu));
-    rec[X.refLen + 1u] = (int)X.P.launchStamp;
+    rec[X.refLen + 1u] = (int)X.launchStamp;
   }
 }
 // the record of the Trail in buffer `src` goes with a copy of that Trail into buffer `dst`
@@ -1368,18 +1372,28 @@ TALC_D double shfl_f64(double v, int src) {   // src is wave-uniform
 // create child `c` of the new set from Trail `t` of the current set with base `b`; sequences have
 // length len -> len+1.  inherit: the child takes over the parent's sequence buffer (it is the
 // parent's last successor).  Returns the child's tip k-mer (wave-uniform).
+// a Trail that is not its parent's last successor: a buffer of its own with a copy of the parent's `len` bases (and, in a
+// bridge search, of the parent's kept alignment row).  A real call: branching is the rare case of the step.
+TALC_DN uint32_t branch_copy(uint32_t parentBuf_, int len_, bool bridge_) {
+  const uint32_t parentBuf = (uint32_t)uni((int)parentBuf_);
+  const int len = uni(len_);
+  const uint32_t cbuf = (uint32_t)pool_alloc();
+  WSYNC();   // bases appended by lane 0 in earlier steps must be visible to the copying lanes
+  wave_copy(X.seqPool + (uint64_t)cbuf * X.C.seqCap, X.seqPool + (uint64_t)parentBuf * X.C.seqCap, (uint32_t)len);
+  if (uni((int)bridge_) != 0) row_copy(cbuf, parentBuf);
+  return cbuf;
+}
+
+// BRIDGE: the step of a bridge search (a copied Trail takes its kept alignment row along; an instance of its own, so
+// that the edge step carries neither the call nor the registers held across it)
+template <bool BRIDGE>
 TALC_D void make_child(int t, int c, int b, int len, uint32_t count, double distAdd, bool inherit, uint64_t& km2,
                        uint64_t& nm2) {
   const uint32_t K = X.P.K;
   const uint64_t kmask = (1ULL << (2 * K)) - 1;
   const TrailRec p = tr_get(X.ia, t);
   uint32_t cbuf = p.buf;
-  if (!inherit) {
-    cbuf = (uint32_t)pool_alloc();
-    WSYNC();   // bases appended by lane 0 in earlier steps must be visible to the copying lanes
-    wave_copy(X.seqPool + (uint64_t)cbuf * X.C.seqCap, X.seqPool + (uint64_t)p.buf * X.C.seqCap, (uint32_t)len);
-    if (uni((int)X.location) == LOC_INNER) row_copy(cbuf, p.buf);
-  }
+  if (!inherit) cbuf = (uint32_t)uni((int)branch_copy(p.buf, len, BRIDGE));
   if (X.dirRight) { km2 = ((p.kmer << 2) | (uint64_t)b) & kmask; nm2 = p.nmask >> 1; }
   else { km2 = ((uint64_t)b << (2 * (K - 1))) | (p.kmer >> 2); nm2 = (p.nmask << 1) & ((1ULL << K) - 1); }
   if (lane_id() == 0) {
@@ -1484,6 +1498,29 @@ TALC_DN int score_bridge_rows(uint32_t buf_, int tlen_, int m_) {
   return sc;
 }
 
+// scoreBridges (Explorer.cpp:689-706): reference truncated to K+step+WINDOW (growth-order prefix).  (A function of its
+// own: it only runs in complex regions, and the step's common path should not carry its registers.)
+TALC_DN void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_) {
+  const DevParams& P = X.P;
+  const int ib = uni(ib_), nNew = uni(nNew_), len = uni(len_);
+  const uint32_t stepCounter = (uint32_t)uni((int)stepCounter_);
+  const int l = lane_id();
+  {
+    const uint32_t bound = P.K + stepCounter + P.WINDOW;
+    const int tlen = (int)min(bound, X.refLen);
+    WSYNC();
+    const uint32_t rowAvail = ((uint32_t)(len + 1) < 4096u) ? (uint32_t)uni((int)X.rowAvail) : 0u;
+    for (int j = 0; j < nNew; ++j) {
+      TrailRec r = tr_get(ib, j);
+      const uint32_t rb = (uint32_t)uni((int)r.buf);
+      if (rb < rowAvail) r.score = score_bridge_rows(rb, tlen, len + 1);
+      else r.score = nw_score(X.ref, tlen, X.seqPool + (uint64_t)rb * X.C.seqCap, len + 1, 4, -3, -2, true);
+      if (l == 0) tr_put(ib, j, r);
+    }
+    WSYNC();
+  }
+}
+
 TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   PROF_DECL;
   const DevParams& P = X.P;
@@ -1520,7 +1557,7 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
         if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
         PROF_BEGIN();
         uint64_t km2, nm2;
-        make_child(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
+        make_child<true>(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
         PROF_END(PF_CHILD);
         // checkAims (Trail.cpp:273-285): first aim whose k-mer equals the child's tip
         int hit = -1;
@@ -1572,20 +1609,8 @@ TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   ++stepCounter;
   int nOut;
   if (complex & (stepCounter % P.CHECK_INTERVAL == 0)) {
-    // scoreBridges (Explorer.cpp:689-706): reference truncated to K+step+WINDOW (growth-order prefix)
-    const uint32_t bound = P.K + stepCounter + P.WINDOW;
-    const int tlen = (int)min(bound, X.refLen);
     PROF_BEGIN();
-    WSYNC();
-    const uint32_t rowAvail = ((uint32_t)(len + 1) < 4096u) ? (uint32_t)uni((int)X.rowAvail) : 0u;
-    for (int j = 0; j < nNew; ++j) {
-      TrailRec r = tr_get(ib, j);
-      const uint32_t rb = (uint32_t)uni((int)r.buf);
-      if (rb < rowAvail) r.score = score_bridge_rows(rb, tlen, len + 1);
-      else r.score = nw_score(X.ref, tlen, X.seqPool + (uint64_t)rb * X.C.seqCap, len + 1, 4, -3, -2, true);
-      if (l == 0) tr_put(ib, j, r);
-    }
-    WSYNC();
+    score_bridges(ib, nNew, len, stepCounter);
     PROF_END(PF_SCOREBR);
     bool cx = false;
     PROF_BEGIN();
@@ -1688,7 +1713,7 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
         if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
         PROF_BEGIN();
         uint64_t km2, nm2;
-        make_child(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
+        make_child<false>(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
         PROF_END(PF_CHILD);
         PROF_BEGIN();
         const bool cycle = uni((int)is_cycle(t, nNew, len, km2, nm2)) != 0;
@@ -2406,7 +2431,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
          const uint32_t* __restrict__ regions, const uint64_t* __restrict__ regoff, uint8_t* __restrict__ outAll,
          const uint64_t* __restrict__ outoff, const uint32_t* __restrict__ order, uint32_t n_work,
          uint32_t* __restrict__ queue, uint8_t* __restrict__ scratchAll, uint64_t* __restrict__ counters, TraceBuf trace,
-         uint32_t traceRead) {
+         uint32_t traceRead, uint32_t launchStamp, uint32_t flags) {
   __shared__ uint32_t s_next;
   const int l = lane_id();
   uint8_t* slot = scratchAll + (uint64_t)blockIdx.x * C.slotBytes;
@@ -2421,7 +2446,8 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.edgeLong = slot + C.o_edgeLong; X.edgeShort = slot + C.o_edgeShort; X.edgeTmp = slot + C.o_edgeTmp;
   X.dpG = (int*)(slot + C.o_dp);
   X.wideBloom = (unsigned long long*)(slot + C.o_wideBloom); X.wideMask = 0;
-  X.rowPool = (P.flags & 1u) ? nullptr : (int*)(slot + C.o_rowPool); X.rowStride = 0; X.rowAvail = 0;   // (flags bit 0: TALC_NO_ROWS)
+  X.rowPool = (flags & 1u) ? nullptr : (int*)(slot + C.o_rowPool); X.rowStride = 0; X.rowAvail = 0;   // (flags bit 0: TALC_NO_ROWS)
+  X.launchStamp = launchStamp;
   X.searchNo = 16u;   // (stamps below 16 << 12 could be matrix values)
   {
     uint8_t* g = slot + C.o_gard;
