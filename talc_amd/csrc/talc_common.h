@@ -10,8 +10,10 @@
 #define TALC_D __device__ __forceinline__
 #ifdef TALC_NO_NOINLINE
 #define TALC_DN __device__ __forceinline__
+#define TALC_DNC __device__ __forceinline__
 #else
 #define TALC_DN __device__ __attribute__((noinline))
+#define TALC_DNC __device__ __attribute__((noinline, cold))   /* rarely executed: optimised for size, laid out apart */
 #endif
 #else
 #define TALC_HD inline

@@ -613,7 +613,7 @@ TALC_D int* dp_array(int which, int need) {
 }
 
 #define NW_REG_NB 12
-TALC_DN int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int match, int mismatch, int gap,
+TALC_DNC int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int match, int mismatch, int gap,
                     bool freeBegin) {
   la = uni(la); lb = uni(lb);
   // the longer sequence spans the lanes (the score is symmetric in its arguments)
@@ -800,7 +800,7 @@ TALC_D void row_set_covered(uint32_t buf, uint32_t covered) {
   }
 }
 // the record of the Trail in buffer `src` goes with a copy of that Trail into buffer `dst`
-TALC_DN void row_copy(uint32_t dst_, uint32_t src_) {
+TALC_DNC void row_copy(uint32_t dst_, uint32_t src_) {
   const uint32_t dst = (uint32_t)uni((int)dst_), src = (uint32_t)uni((int)src_);
   const uint32_t avail = (uint32_t)uni((int)X.rowAvail);
   if (dst >= avail) return;
@@ -811,14 +811,14 @@ TALC_DN void row_copy(uint32_t dst_, uint32_t src_) {
 }
 // slots >= HOT live in HBM; these are real calls so that the optimiser never merges an LDS and an
 // HBM access into one access through a pointer of mixed provenance (which would become flat_*)
-TALC_DN TrailRec tr_get_slow(int set, int t) {
+TALC_DNC TrailRec tr_get_slow(int set, int t) {
   const TrailSet& S = X.G[set];
   TrailRec r;
   r.kmer = S.kmer[t]; r.nmask = S.nmask[t]; r.dist = S.dist[t]; r.cnt = S.cnt[t]; r.score = S.score[t]; r.fail = S.fail[t];
   r.lanc = S.lanc[t]; r.ranc = S.ranc[t]; r.buf = S.buf[t];
   return r;
 }
-TALC_DN void tr_put_slow(int set, int t, TrailRec r) {
+TALC_DNC void tr_put_slow(int set, int t, TrailRec r) {
   TrailSet& S = X.G[set];
   S.kmer[t] = r.kmer; S.nmask[t] = r.nmask; S.dist[t] = r.dist; S.cnt[t] = r.cnt; S.score[t] = r.score; S.fail[t] = r.fail;
   S.lanc[t] = r.lanc; S.ranc[t] = r.ranc; S.buf[t] = r.buf;
@@ -878,7 +878,7 @@ TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
 // ------------------------------------------------------------------ anchors (Explorer.cpp:413-543)
 // side 0: anchorLEFTHandSide (walks the LEFT region leftwards from its end, degree towards RIGHT)
 // side 1: anchorRIGHTHandSide (walks the RIGHT region rightwards from its start, degree towards LEFT)
-TALC_DN void sort_anchors_long(AnchorRec* anc, int n, double cc) { gnu_sort(anc, n, LessAnchor{cc}); }
+TALC_DNC void sort_anchors_long(AnchorRec* anc, int n, double cc) { gnu_sort(anc, n, LessAnchor{cc}); }
 
 TALC_DN void build_anchors(int side) {
   PROF_DECL;
@@ -1135,7 +1135,7 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
   return r;
 }
 
-TALC_DN SeedExt seed_and_extension_wide(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
+TALC_DNC SeedExt seed_and_extension_wide(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
   return seed_and_extension_body<true>(ref, refLen, cand, candLen, xdrop, withScore);
 }
 TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
@@ -1374,7 +1374,7 @@ TALC_D double shfl_f64(double v, int src) {   // src is wave-uniform
 // parent's last successor).  Returns the child's tip k-mer (wave-uniform).
 // a Trail that is not its parent's last successor: a buffer of its own with a copy of the parent's `len` bases (and, in a
 // bridge search, of the parent's kept alignment row).  A real call: branching is the rare case of the step.
-TALC_DN uint32_t branch_copy(uint32_t parentBuf_, int len_, bool bridge_) {
+TALC_DNC uint32_t branch_copy(uint32_t parentBuf_, int len_, bool bridge_) {
   const uint32_t parentBuf = (uint32_t)uni((int)parentBuf_);
   const int len = uni(len_);
   const uint32_t cbuf = (uint32_t)pool_alloc();
@@ -1431,7 +1431,7 @@ TALC_D void swap_sets() { X.ia ^= 1; }
 
 // doABitOfGardening on the new set (n trails); survivors are copied into the other set, which
 // becomes the current one; returns their number
-TALC_DN int garden(int n, int len, bool& isComplex) {
+TALC_DNC int garden(int n, int len, bool& isComplex) {
   __shared__ int s_nk;
   __shared__ int s_cx;
   const int l = lane_id();
@@ -1472,7 +1472,7 @@ TALC_D int last_successor(int tags) {
 // Explorer::oneMoreStep (Explorer.cpp:546-612).  nCur trails of length len in the current set.
 // Trail::Overlapscore (Trail.cpp:145-173) of the Trail in buffer `buf` (m bases) against the first tlen bases of the
 // reference, from the row the Trail (or the Trail it was copied from) left at its last scoring
-TALC_DN int score_bridge_rows(uint32_t buf_, int tlen_, int m_) {
+TALC_DNC int score_bridge_rows(uint32_t buf_, int tlen_, int m_) {
   const uint32_t buf = (uint32_t)uni((int)buf_);
   const int tlen = uni(tlen_), m = uni(m_);
   const int n = (int)uni((int)X.refLen);
@@ -1500,7 +1500,7 @@ TALC_DN int score_bridge_rows(uint32_t buf_, int tlen_, int m_) {
 
 // scoreBridges (Explorer.cpp:689-706): reference truncated to K+step+WINDOW (growth-order prefix).  (A function of its
 // own: it only runs in complex regions, and the step's common path should not carry its registers.)
-TALC_DN void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_) {
+TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_) {
   const DevParams& P = X.P;
   const int ib = uni(ib_), nNew = uni(nNew_), len = uni(len_);
   const uint32_t stepCounter = (uint32_t)uni((int)stepCounter_);
@@ -2110,7 +2110,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
 }
 
 // (the long searches' instances: a function of their own, so that the common one's code stays together)
-TALC_DN int fast_forward_wide(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
+TALC_DNC int fast_forward_wide(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
   return uni((int)X.dirRight) ? fast_forward_walk<true, true>(len, stepCounter, PATH_MAXLENGTH, edge)
                               : fast_forward_walk<false, true>(len, stepCounter, PATH_MAXLENGTH, edge);
 }
