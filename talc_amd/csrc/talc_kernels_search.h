@@ -641,8 +641,25 @@ TALC_DNC int nw_score(const uint8_t* a, int la, const uint8_t* b, int lb, int ma
   return r;
 }
 
-// edit score (globalAlignment 0/-1/-1) and LCS length (localAlignment 1/0/0) of the same pair
 #define NW2_REG_NB 8
+// the lane-skewed sweeps behind edit_and_lcs (what is left when neither the wavefront nor the bit-vector routines apply:
+// a cold call); returns editScore | lcsLen << 32 for the parts not yet known
+TALC_DNC unsigned long long edit_and_lcs_sweep(const uint8_t* a, int la_, const uint8_t* b, int lb_, bool haveEdit_, bool haveLcs_) {
+  const int la = uni(la_), lb = uni(lb_);
+  const bool haveEdit = uni((int)haveEdit_) != 0, haveLcs = uni((int)haveLcs_) != 0;
+  int editScore = 0, lcsLen = 0;
+  if (!haveEdit && !haveLcs && la <= 64 * NW2_REG_NB) {
+    unsigned long long ncells = 0;
+    wave_edit_lcs_reg<NW2_REG_NB>(a, la, b, lb, editScore, lcsLen, ncells);
+    X.cells += ncells;
+  } else {
+    if (!haveEdit) editScore = nw_score(a, la, b, lb, 0, -1, -1, false);
+    if (!haveLcs) lcsLen = nw_score(a, la, b, lb, 1, 0, 0, false);
+  }
+  return ((unsigned long long)(uint32_t)uni(lcsLen) << 32) | (uint32_t)uni(editScore);
+}
+
+// edit score (globalAlignment 0/-1/-1) and LCS length (localAlignment 1/0/0) of the same pair
 // needEdit = false: only the LCS is wanted (the caller does not use the edit score: a single bridge candidate is not
 // compared with anything, Trajectory.cpp:282-303; an edge whose extension stopped takes the extension's own score,
 // Trail.cpp:408-434) — editScore is then left at 0.
@@ -711,14 +728,9 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
     if (ed >= 0) { editScore = -ed; haveEdit = true; X.cells += ncells; }
   }
   if (haveEdit && haveLcs) return;
-  if (!haveEdit && !haveLcs && la <= 64 * NW2_REG_NB) {
-    unsigned long long ncells = 0;
-    wave_edit_lcs_reg<NW2_REG_NB>(a, la, b, lb, editScore, lcsLen, ncells);
-    X.cells += ncells;
-    return;
-  }
-  if (!haveEdit) editScore = nw_score(a, la, b, lb, 0, -1, -1, false);
-  if (!haveLcs) lcsLen = nw_score(a, la, b, lb, 1, 0, 0, false);
+  const unsigned long long packed = edit_and_lcs_sweep(a, la, b, lb, haveEdit, haveLcs);   // (never reached with the HBM arrays in place)
+  if (!haveEdit) editScore = (int)(uint32_t)packed;
+  if (!haveLcs) lcsLen = (int)(uint32_t)(packed >> 32);
 }
 
 // ------------------------------------------------------------------ trace helpers
@@ -1022,6 +1034,29 @@ TALC_DN void build_anchors(int side) {
   PROF_END(PF_ANCHORS);
 }
 
+// the anti-diagonal form of the x-drop extension (anti-diagonals in LDS, or in HBM when too long): the fallback for a band
+// wider than the wavefront routines take (a real, cold call: it keeps two instances of the sweep out of the extension's code);
+// returns extCols | extRows << 32
+TALC_DNC unsigned long long xdrop_sweep(const uint8_t* q, int qlen_, const uint8_t* d, int dlen_, int xdrop_) {
+  const int qlen = uni(qlen_), dlen = uni(dlen_), xdrop = uni(xdrop_);
+  q = uni_ptr(q); d = uni_ptr(d);
+  const int need = qlen + 3;
+  int extCols = 0, extRows = 0;
+  unsigned long long ncells = 0;
+  if (need <= LDS_DP_CAP) {
+    XDropBufT<int TALC_AS3*> buf;
+    buf.d1 = (int TALC_AS3*)g_dp; buf.d2 = buf.d1 + LDS_DP_CAP; buf.d3 = buf.d2 + LDS_DP_CAP;
+    wave_xdrop<int TALC_AS3*, true>(q, qlen, d, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, ncells);
+  } else {
+    XDropBuf buf;
+    buf.d1 = dp_array(0, need); buf.d2 = dp_array(1, need); buf.d3 = dp_array(2, need);
+    if (!((uint32_t)need > X.C.dpCap))
+      wave_xdrop<int*, false>(q, qlen, d, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, ncells);
+  }
+  X.cells += ncells;
+  return ((unsigned long long)(uint32_t)uni(extRows) << 32) | (uint32_t)uni(extCols);
+}
+
 // ------------------------------------------------------------------ getSeedAndExtension (Trail.cpp:341-437)
 struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extRef, extCand; };
 
@@ -1074,7 +1109,7 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
       }
     }
     else if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
-    else if (ndiagonals <= 255 && X.C.dpCap >= 2048u) {
+    else if (ndiagonals <= 255) {   // (the hand-over state lives in the HBM DP arrays: make_caps keeps them at 2048 ints or more)
       // in phases (WfaPhase): levels 0..31 one diagonal per lane, 32..63 two, the rest four
       int* mem = X.dpG + 2ull * X.C.dpCap + 256;   // (past the flags of the multi-x run)
       WfaPhase ph{-1, 31, mem, mem + 512};
@@ -1088,22 +1123,11 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
         }
       }
     }
-    else if (ndiagonals <= 127) rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
-    else if (ndiagonals <= 255) rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
     else rc = -1;
-    if (rc < 0) {   // band wider than a wavefront (x-drop above ~30): anti-diagonals in LDS, or in HBM when too long
-      const int need = qlen + 3;
-      extCols = extRows = 0; rc = -1;
-      if (need <= LDS_DP_CAP) {
-        XDropBufT<int TALC_AS3*> buf;
-        buf.d1 = (int TALC_AS3*)g_dp; buf.d2 = buf.d1 + LDS_DP_CAP; buf.d3 = buf.d2 + LDS_DP_CAP;
-        wave_xdrop<int TALC_AS3*, true>(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, ncells);
-      } else {
-        XDropBuf buf;
-        buf.d1 = dp_array(0, need); buf.d2 = dp_array(1, need); buf.d3 = dp_array(2, need);
-        if (!((uint32_t)need > X.C.dpCap))
-          wave_xdrop<int*, false>(seq2 + S, qlen, seq1 + S, dlen, 0, -1, -1, xdrop, buf, extCols, extRows, ncells);
-      }
+    if (rc < 0) {   // band wider than the wavefront routines take: the anti-diagonal sweep
+      rc = -1;
+      const unsigned long long packed = xdrop_sweep(seq2 + S, qlen, seq1 + S, dlen, xdrop);
+      extCols = (int)(uint32_t)packed; extRows = (int)(uint32_t)(packed >> 32);
     }
     PROF_END(PF_XDROP);
     X.cells += ncells;
@@ -1145,7 +1169,7 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
     const int qlen = min(rl, cl) - S, dlen = max(rl, cl) - S;
     if (qlen > 0 && dlen > 0) {
       const int nd = min(x, qlen) + min(x, dlen) + 1;
-      if (nd > 255 && nd <= 511 && uni((int)X.C.dpCap) >= 2048) [[clang::musttail]] return seed_and_extension_wide(ref, refLen, cand, candLen, xdrop, withScore);
+      if (nd > 255 && nd <= 511) [[clang::musttail]] return seed_and_extension_wide(ref, refLen, cand, candLen, xdrop, withScore);
     }
   }
   return seed_and_extension_body<false>(ref, refLen, cand, candLen, xdrop, withScore);
