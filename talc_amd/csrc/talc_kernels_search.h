@@ -2133,7 +2133,12 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   return done;
 }
 
-// (the long searches' instances: a function of their own, so that the common one's code stays together)
+// (the per-step form — tables too large for walk records, or a MIN_COUNT beyond their fields — and the long searches'
+//  instances: functions of their own, so that the common one's code stays together)
+TALC_DN int fast_forward_steps(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
+  return uni((int)X.dirRight) ? fast_forward_dir<true>(len, stepCounter, PATH_MAXLENGTH, edge)
+                              : fast_forward_dir<false>(len, stepCounter, PATH_MAXLENGTH, edge);
+}
 TALC_DNC int fast_forward_wide(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
   return uni((int)X.dirRight) ? fast_forward_walk<true, true>(len, stepCounter, PATH_MAXLENGTH, edge)
                               : fast_forward_walk<false, true>(len, stepCounter, PATH_MAXLENGTH, edge);
@@ -2146,8 +2151,7 @@ TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH
     return uni((int)X.dirRight) ? fast_forward_walk<true, false>(len, stepCounter, PATH_MAXLENGTH, edge)
                                 : fast_forward_walk<false, false>(len, stepCounter, PATH_MAXLENGTH, edge);
   }
-  return uni((int)X.dirRight) ? fast_forward_dir<true>(len, stepCounter, PATH_MAXLENGTH, edge)
-                              : fast_forward_dir<false>(len, stepCounter, PATH_MAXLENGTH, edge);
+  [[clang::musttail]] return fast_forward_steps(len, stepCounter, PATH_MAXLENGTH, edge);
 }
 
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
