@@ -414,6 +414,11 @@ int talc_table_upload(talc_table* t, int device) {
       hipLaunchKernelGGL(k_build_filter, dim3((unsigned)((t->h.capacity + 255) / 256)), dim3(256), 0, 0, dc.right, t->h.capacity,
                          t->h.p.k, (unsigned long long*)dc.filter, dc.filterWords);
     HIPCHK(hipGetLastError());
+    // ... and every RIGHT bucket's in-degree into its key word (talc_common.h: the coverage kernel's left degrees)
+    if (t->h.capacity)
+      hipLaunchKernelGGL(k_build_indegree, dim3((unsigned)((t->h.capacity + 255) / 256)), dim3(256), 0, 0, dc.right, dc.left, t->h.capacity,
+                         (uint32_t)t->h.p.min_count);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
   }
   // walk tables (WalkEntry, talc_common.h): twice the bucket tables' size again.  Built when they leave the correction

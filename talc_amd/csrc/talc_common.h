@@ -54,6 +54,12 @@ struct __attribute__((aligned(32))) Bucket {
 static_assert(sizeof(Bucket) == 32, "bucket must be 32 bytes");
 
 static const uint64_t kEmptyKey = ~0ULL;
+// A key takes 2 (K - 1) <= 60 bits.  The top three bits of a RIGHT bucket's key word on the DEVICE hold the in-degree of
+// its (K-1)-mer — how many of the four predecessors b + key have a count >= the table's MIN_COUNT, i.e. what the LEFT
+// bucket of the same key would say (k_build_indegree, at upload) — so that the coverage kernel learns a k-mer's count
+// and its left degree from ONE bucket.  Every key comparison masks them (an empty key never equals a masked key).
+static const uint64_t kKeyMask = (1ULL << 61) - 1;
+static const int kKeyDegShift = 61;
 
 // coverage word pair per k-mer position: {count, colour (16 bits) | out-degrees}.  For a k-mer that is in the table
 // (count != 0) k_coverage adds its out-degree towards RIGHT and towards LEFT (0..4 each) and the "known" flag.

@@ -119,7 +119,7 @@ TALC_D uint64_t dev_find_slot(const Bucket* tab, uint64_t cap, uint64_t key) {
   uint64_t i = table_home(key, cap);
   while (true) {
     const uint64_t k = ((const uint64_t TALC_AS1*)&tab[i].key)[0];
-    if (k == key) return i;
+    if ((k & kKeyMask) == key) return i;
     if (k == kEmptyKey) return ~0ULL;
     if (++i == cap) i = 0;
   }
@@ -191,14 +191,29 @@ __global__ void k_build_filter(const Bucket* __restrict__ right, uint64_t cap, u
   if (j >= cap) return;
   const BucketRegs r = load_bucket(right + j);
   if (r.key == kEmptyKey) return;
+  const uint64_t key = r.key & kKeyMask;
   const uint64_t nBlocks = nWords >> 3;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     if (r.cnt[b] == 0) continue;
-    const uint64_t km = (r.key << 2) | (uint64_t)b;
+    const uint64_t km = (key << 2) | (uint64_t)b;
     const FilterHash h = filter_hash(km);
     atomicOr(&filter[filter_index(km, K, h, nBlocks)], (unsigned long long)filter_mask(h));
   }
+}
+
+// in-degree of every RIGHT bucket's (K-1)-mer into the top bits of its key word (talc_common.h), one thread per bucket
+__global__ void k_build_indegree(Bucket* __restrict__ right, const Bucket* __restrict__ left, uint64_t cap, uint32_t min_count) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cap) return;
+  unsigned long long TALC_AS1* kp = (unsigned long long TALC_AS1*)&right[j].key;
+  const uint64_t raw = *kp;
+  if (raw == kEmptyKey) return;
+  const uint64_t key = raw & kKeyMask;
+  BucketRegs rl;
+  uint64_t deg = 0;
+  if (probe_bucket(left, cap, key, rl)) deg = (rl.cnt[0] >= min_count) + (rl.cnt[1] >= min_count) + (rl.cnt[2] >= min_count) + (rl.cnt[3] >= min_count);
+  *kp = key | (deg << kKeyDegShift);
 }
 
 // ------------------------------------------------------------------ walk tables (WalkEntry, talc_common.h)
@@ -224,7 +239,7 @@ __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __r
   const Bucket* tab = dirRight ? right : left;
   const uint64_t m1 = (1ULL << (2 * (K - 1))) - 1;
   BucketRegs r = load_bucket(tab + s);
-  const uint64_t key0 = r.key;
+  const uint64_t key0 = (r.key == kEmptyKey) ? kEmptyKey : (r.key & kKeyMask);
   uint32_t lv[TALC_WALK_LEVELS];
 #pragma unroll
   for (int i = 0; i < TALC_WALK_LEVELS; ++i) lv[i] = 0;

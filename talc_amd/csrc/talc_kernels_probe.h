@@ -31,7 +31,7 @@ TALC_D bool probe_bucket(const Bucket* tab, uint64_t cap, uint64_t key, BucketRe
   uint64_t i = dev_home(key, cap);
   while (true) {
     BucketRegs r = load_bucket(tab + i);
-    if (r.key == key) { out = r; return true; }
+    if ((r.key & kKeyMask) == key) { out = r; return true; }
     if (r.key == kEmptyKey) return false;
     if (++i == cap) i = 0;
   }
@@ -40,7 +40,7 @@ TALC_D bool probe_bucket(const Bucket* tab, uint64_t cap, uint64_t key, BucketRe
 // the same, the home bucket `r` (slot i) having been loaded by the caller (several probes' first loads in flight together)
 TALC_D bool probe_bucket_from(const Bucket* tab, uint64_t cap, uint64_t key, uint64_t i, BucketRegs& r) {
   while (true) {
-    if (r.key == key) return true;
+    if ((r.key & kKeyMask) == key) return true;
     if (r.key == kEmptyKey) return false;
     if (++i == cap) i = 0;
     r = load_bucket(tab + i);
@@ -119,25 +119,26 @@ __global__ void k_encode(const uint8_t* __restrict__ raw, uint8_t* __restrict__ 
 // The table part of one lookup, for a k-mer that passed the filter: its count and colour, and — for a k-mer of the
 // table — its out-degrees in both directions (getOutDegree, Jellyfish.cpp:383-393, for this MIN_COUNT), which ride in
 // the colour word's upper half: the anchor search asks for them position by position (Explorer.cpp:449,515) and would
-// otherwise probe, one dependent access at a time.  Three buckets are involved: RIGHT[prefix] (the count), LEFT[prefix]
-// (the predecessors' counts) and RIGHT[suffix] (the successors' counts) — and RIGHT[suffix] of position p is
+// otherwise probe, one dependent access at a time.  Three buckets would be involved — RIGHT[prefix] (the count),
+// LEFT[prefix] (the predecessors' counts), RIGHT[suffix] (the successors' counts) — but RIGHT[suffix] of position p is
 // RIGHT[prefix] of position p + 1, which that position's own lookup reads anyway when it is in the queue too (nine in
 // ten positions inside a solid region): cov_count publishes the successor degree its bucket implies for the position
 // before it, and cov_degrees only probes when nobody did.
 TALC_D uint32_t bucket_degree(const BucketRegs& r, uint32_t min_count) {
   return (r.cnt[0] >= min_count) + (r.cnt[1] >= min_count) + (r.cnt[2] >= min_count) + (r.cnt[3] >= min_count);
 }
-// step 1: count, colour, left degree; degPrev = the right degree of the PREVIOUS position's k-mer
+// step 1: count, colour, left degree; degPrev = the right degree of the PREVIOUS position's k-mer.  ONE bucket: the
+// RIGHT bucket of the k-mer's prefix holds the count, its key word's top bits the prefix's in-degree (= the k-mer's left
+// degree: what LEFT[prefix] would say, talc_common.h), its four counts the previous position's right degree.
 TALC_D void cov_count(const TableView& T, uint64_t kmer, uint32_t min_count, uint32_t& c, uint32_t& j, uint32_t& dL, uint32_t& degPrev) {
   c = 0; j = 0; dL = 0; degPrev = 0;
   const uint64_t kp = kmer >> 2;
-  const uint64_t ip = dev_home(kp, T.capacity);
-  BucketRegs rc = load_bucket(T.right + ip), rl = load_bucket(T.left + ip);   // both requested before either is used
-  if (!probe_bucket_from(T.right, T.capacity, kp, ip, rc)) return;            // no successor of that (K-1)-mer at all
+  BucketRegs rc;
+  if (!probe_bucket(T.right, T.capacity, kp, rc)) return;            // no successor of that (K-1)-mer at all
   degPrev = bucket_degree(rc, min_count);
   const int b = (int)(kmer & 3);
   c = rc.cnt[b]; j = rc.jc(b);
-  if (c != 0 && probe_bucket_from(T.left, T.capacity, kp, ip, rl)) dL = bucket_degree(rl, min_count);
+  if (c != 0) dL = (uint32_t)(rc.key >> kKeyDegShift);
 }
 // step 2 (only for c != 0, when the next position did not publish it): the right degree by its own probe
 TALC_D uint32_t cov_right_degree(const TableView& T, uint64_t kmer, uint32_t min_count) {

@@ -1851,7 +1851,7 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
     bool found = false;
     while (true) {
       const uint64_t bk = ((uint64_t)b[1] << 32) | b[0];
-      if (bk == key) { found = true; break; }
+      if ((bk & kKeyMask) == key) { found = true; break; }
       if (bk == kEmptyKey) break;
       if (++slot == cap) slot = 0;
       b = *(const v8u32 TALC_AS4*)(tab + slot);

@@ -68,7 +68,7 @@ struct HostTable {
   static inline bool findSlotBounded(Bucket* tab, uint64_t cap, uint64_t key, uint64_t limit, uint64_t& slot) {
     uint64_t i = home(key, cap);
     while (i < limit) {
-      if (tab[i].key == key || tab[i].key == kEmptyKey) { slot = i; return true; }
+      if ((tab[i].key & kKeyMask) == key || tab[i].key == kEmptyKey) { slot = i; return true; }
       ++i;
     }
     return false;
@@ -76,14 +76,14 @@ struct HostTable {
   static inline void findSlot(Bucket* tab, uint64_t cap, uint64_t key, uint64_t& slot) {
     uint64_t i = home(key, cap);
     while (true) {
-      if (tab[i].key == key || tab[i].key == kEmptyKey) { slot = i; return; }
+      if ((tab[i].key & kKeyMask) == key || tab[i].key == kEmptyKey) { slot = i; return; }
       if (++i == cap) i = 0;
     }
   }
   static inline const Bucket* find(const Bucket* tab, uint64_t cap, uint64_t key) {
     uint64_t i = home(key, cap);
     while (true) {
-      if (tab[i].key == key) return &tab[i];
+      if ((tab[i].key & kKeyMask) == key) return &tab[i];   // (an image that came back from a device carries degree bits)
       if (tab[i].key == kEmptyKey) return nullptr;
       if (++i == cap) i = 0;
     }
