@@ -133,8 +133,11 @@ TALC_HD uint64_t table_home(uint64_t key, uint64_t cap) { return table_slot(tabl
 #ifndef TALC_FILTER_MINIMIZER
 #define TALC_FILTER_MINIMIZER 1
 #endif
+#ifndef TALC_MINIMIZER_SPAN
+#define TALC_MINIMIZER_SPAN 7   /* M = K - span: a k-mer has span + 1 M-mers */
+#endif
 TALC_HD uint32_t filter_mmer_len(uint32_t K) {
-  uint32_t m = K > 7 ? K - 7 : 1;
+  uint32_t m = K > TALC_MINIMIZER_SPAN ? K - TALC_MINIMIZER_SPAN : 1;
   m = m < 12 ? 12 : (m > 16 ? 16 : m);
   return m < K ? m : K;
 }
