@@ -103,12 +103,12 @@ __global__ void k_encode(const uint8_t* __restrict__ raw, uint8_t* __restrict__ 
 // One block per tile of up to COV_TILE consecutive k-mer positions of ONE read, in two phases:
 //  A. the tile's base window (COV_TILE + K - 1 codes) is staged into LDS as 2-bit packed words (first base most
 //     significant, so a k-mer is one funnel shift away from its table form) plus an N bitmap; thread t takes positions
-//     t, t+256, ...: k-mer, presence-filter test (one 8-byte word of a cache-resident array), and either an 8-byte
+//     t, t+256, ...: k-mer, presence-filter test (one 8-byte word of a block its minimizer chooses: lanes share lines), and either an 8-byte
 //     (0, 0) store — coalesced across the wave — or, for the 7-9 % that may be in the table, an entry in an LDS queue;
-//  B. the queue is worked off with every lane busy: the 32-byte bucket of the k-mer's (K-1)-prefix (the only random HBM
-//     access of a lookup) and, for a k-mer that is in the table, the two buckets that give its out-degrees; the result
-//     overwrites the position's (0, 0).  Doing this inside phase A would run the whole probe sequence — three table
-//     hashes with 64-bit multiplies — on every iteration of every wave for one lane in twelve.
+//  B. the queue is worked off with every lane busy: the 32-byte bucket of the k-mer's (K-1)-prefix — the one random HBM
+//     access of a lookup: it holds the count, the k-mer's left degree (key word's top bits) and the right degree of the
+//     position before (published through LDS; cov_count below); the result overwrites the position's (0, 0).  Doing
+//     this inside phase A would run the probe sequence on every iteration of every wave for one lane in twelve.
 //  #{count > MIN_COUNT} (Read.cpp:190) is reduced per block and added to the read's counter.
 #define COV_TILE 2048
 #define COV_THREADS 256
