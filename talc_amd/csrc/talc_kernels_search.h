@@ -2792,6 +2792,34 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
       }
     }
     if (lane_id() == 0) { out[0] = ok ? 1 : 0; out[1] = nbad; out[2] = first; out[5] = (int)X.overflow; }
+  } else if (mode == 7) {
+    // mode 7: scoreBridges' alignment continued row by row (wave_nw_rows) against the alignment from scratch (nw_score):
+    // a = the reference, b = the candidate; for m = p0, p0 + p2, ... <= lb the kept row (behind the DP arrays) is
+    // continued to m rows and its entry at tlen = min(la, m + p3) compared with nw_score(a[0, tlen), b[0, m), free begin).
+    // out[0] = scorings, out[1] = those that differ, out[2] = the first such m
+    int* row = X.dpG + 3ull * X.C.dpCap;
+    int calls = 0, nbad = 0, first = -1, i0 = 0;
+    const int B = (la + 63) >> 6;
+    for (int m = p0; m <= lb && la >= 1 && la <= ROW_MAX_REF; m += max(p2, 1)) {
+      const int tlen = min(la, m + p3);
+      unsigned long long ncells = 0;
+      int sc;
+      WSYNC();
+      if (B <= 2) sc = wave_nw_rows<2>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 4) sc = wave_nw_rows<4>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 6) sc = wave_nw_rows<6>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 8) sc = wave_nw_rows<8>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 12) sc = wave_nw_rows<12>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 16) sc = wave_nw_rows<16>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 24) sc = wave_nw_rows<24>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else sc = wave_nw_rows<32>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      i0 = m;
+      WSYNC();
+      const int ex = nw_score(a, tlen, b, m, 4, -3, -2, true);
+      if (uni(sc) != uni(ex)) { if (first < 0) first = m; ++nbad; }
+      ++calls;
+    }
+    if (lane_id() == 0) { out[0] = calls; out[1] = nbad; out[2] = first; out[5] = (int)X.overflow; }
   } else if (mode == 4) {
     // mode 4: edit_and_lcs(a, b) -> out[0] = global (0,-1,-1) score, out[1] = LCS length
     int es = 0, lcs = 0;

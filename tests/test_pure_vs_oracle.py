@@ -410,3 +410,64 @@ def test_bit_vector_block_hand_over_is_exact():
         for B in (4, 7, 64):
             assert _lcs_blocks(a, b, B) == exp_l and _lcs_blocks(b, a, B) == exp_l, (len(a), len(b), B)
             assert _edit_blocks(a, b, B) == exp_e and _edit_blocks(b, a, B) == exp_e, (len(a), len(b), B)
+
+
+def _nw_rows(ref, cand, i0, m, row):
+    """wave_nw_rows restated: rows i0+1 .. m of the free-begin (4, -3, -2) matrix of `cand` (rows) against the WHOLE
+    `ref` (columns), continued from `row` = row i0 (None: row 0, all zero); returns row m."""
+    n = len(ref)
+    prev = list(row) if row is not None else [0] * (n + 1)
+    for i in range(i0 + 1, m + 1):
+        cur = [0] * (n + 1)                      # column 0 is free
+        for j in range(1, n + 1):
+            d = prev[j - 1] + (4 if ref[j - 1] == cand[i - 1] else -3)
+            cur[j] = max(d, prev[j] - 2, cur[j - 1] - 2)
+        prev = cur
+    return prev
+
+
+def test_alignment_rows_continued_equal_the_alignments_from_scratch():
+    """scoreBridges (Explorer.cpp:689-706) aligns a Trail of K + step bases against the first K + step + WINDOW bases of
+    the reference every CHECK_INTERVAL steps; the device keeps the Trail's last matrix row over the whole reference and
+    only adds the new rows.  A growing candidate, truncations growing with it, rows continued in steps of 1..9 bases:
+    the kept row's entry at the truncation's length equals the oracle's alignment (free begin, end gaps charged) of the
+    candidate's prefix against the truncated reference, every time — the same for a copy that branches off and grows
+    differently."""
+    rnd = random.Random(91)
+    L = O.lib()
+    for it in range(25):
+        n = rnd.choice([30, 64, 65, 200, 330])
+        ref = "".join(rnd.choice("ACGT") for _ in range(n))
+        cand = []
+        for ch in ref:
+            x = rnd.random()
+            if x < 0.05:
+                cand.append(rnd.choice("ACGT"))
+            elif x < 0.10:
+                cand.append(ch)
+                cand.append(rnd.choice("ACGT"))
+            elif x >= 0.15:
+                cand.append(ch)
+        cand = "".join(cand) + "".join(rnd.choice("ACGT") for _ in range(20))
+        window = rnd.choice([5, 10, 15])
+        K = 21
+        row, i0 = None, 0
+        branch = None
+        m = K
+        while m <= len(cand):
+            row = _nw_rows(ref, cand, i0, m, row)
+            i0 = m
+            tlen = min(n, m + window)
+            exp = L.orc_global_alignment(ref[:tlen].encode(), cand[:m].encode(), 4, -3, -2, 1, 1, 0, 0)
+            assert row[tlen] == exp, (n, m, tlen, row[tlen], exp)
+            if branch is None and m > len(cand) // 2:      # a copy branches off here: other bases from now on
+                branch = (list(row), m, cand[:m] + "".join(rnd.choice("ACGT") for _ in range(40)))
+            m += rnd.choice([1, 3, 6, 6, 9])
+        if branch:
+            brow, bi0, bcand = branch
+            for m2 in range(bi0 + 6, len(bcand) + 1, 6):
+                brow = _nw_rows(ref, bcand, bi0, m2, brow)
+                bi0 = m2
+                tlen = min(n, m2 + window)
+                exp = L.orc_global_alignment(ref[:tlen].encode(), bcand[:m2].encode(), 4, -3, -2, 1, 1, 0, 0)
+                assert brow[tlen] == exp, ("branch", n, m2, tlen)
