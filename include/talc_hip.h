@@ -109,7 +109,13 @@ void talc_pinned_free(void* p);
  * k-mers (utils.cpp:658-669).  Lines whose k-mer is not K letters of ACGT can never match a
  * query and are counted in stats but not stored.  A count token that does not start with a number
  * (std::stoi throws in the reference, Jellyfish.cpp:259) reads as 0 here.  stats (may be NULL) receives
- * {lines read, lines kept, malformed lines}. */
+ * {lines read, lines kept, malformed lines}.
+ * Either path may also name a Jellyfish 2 count file (the `.jf` of `jellyfish count`, format "binary/sorted": the file
+ * the reference's jellyfish2 query mode would have asked `jellyfish query` about once per look-up,
+ * Jellyfish.cpp:323-379,415-467,498-552).  It is recognised by its header and read under the same contract (every
+ * record is a "line"; csrc/talc_jf.h); a file that carries that header but does not verify — another format, k-mers
+ * of another length than p->k, a body that is not whole records, padding bits set, a zero count — fails with
+ * TALC_ERR_INVALID and a message, it is never guessed at. */
 int talc_table_build(const char* dump_path, const char* junction_path, const talc_params* p,
                      talc_table** out, int64_t stats[3]);
 

@@ -332,7 +332,9 @@ static int table_build_impl(const char* dump_path, const char* junction_path, co
   std::vector<uint64_t> kmers;
   std::vector<uint32_t> counts;
   DumpStats ds;
-  if (!parseDumpFile(dump_path, p->k, p->min_count, true, kmers, &counts, nullptr, ds)) return fail(TALC_ERR_IO, "cannot open %s", dump_path);
+  std::string why;
+  if (!parseDumpFile(dump_path, p->k, p->min_count, true, kmers, &counts, nullptr, ds, &why))
+    return why.empty() ? fail(TALC_ERR_IO, "cannot open %s", dump_path) : fail(TALC_ERR_INVALID, "%s", why.c_str());
   talc_table* t = nullptr;
   rc = (device >= 0) ? talc_table_from_arrays_device(kmers.data(), counts.data(), kmers.size(), p, device, &t)
                      : talc_table_from_arrays(kmers.data(), counts.data(), kmers.size(), p, &t);
@@ -343,7 +345,10 @@ static int table_build_impl(const char* dump_path, const char* junction_path, co
     std::vector<uint64_t> jk;
     std::vector<int64_t> jc;
     DumpStats js;
-    if (!parseDumpFile(junction_path, p->k, 0, false, jk, nullptr, &jc, js)) { delete t; return fail(TALC_ERR_IO, "cannot open %s", junction_path); }
+    if (!parseDumpFile(junction_path, p->k, 0, false, jk, nullptr, &jc, js, &why)) {
+      talc_table_destroy(t);
+      return why.empty() ? fail(TALC_ERR_IO, "cannot open %s", junction_path) : fail(TALC_ERR_INVALID, "%s", why.c_str());
+    }
     ds.nbad += js.nbad;
     if ((rc = talc_table_colour(t, jk.data(), jc.data(), jk.size()))) { talc_table_destroy(t); return rc; }
   }

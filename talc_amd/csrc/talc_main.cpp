@@ -12,11 +12,16 @@
 //   --read-stats     append the per-read rows of Read::outputBasicReadStats (Read.cpp:418-433) to <o>.stats_basics.txt
 //                    (the reference has that call commented out, main.cpp:305, and only ever writes the header)
 //   -k accepts 18..31 (the reference stops at 30, main.cpp:115-116; 31 still fits 62 bits)
+//   -SR / -j accept a Jellyfish 2 count file (.jf, `jellyfish count` output) as well as the text dump, in either mode
+//   -qm jellyfish2 works (the reference's is dead code): with -jf2 DIR the counts come from `DIR/jellyfish
+//                    dump` (the tool the reference would have queried k-mer by k-mer, Jellyfish.cpp:323-379), without it
+//                    from the native reader of the .jf; with neither a -jf2 nor a .jf the reference's behaviour is kept
 // -t/--num_threads is accepted and ignored (the parallelism is on the device).
 // Differences, all documented in INTEGRATION.md: stdout carries the [TALC] banners but none of
 // the reference's always-on debug dumps; log lines are written in input order.
 #include <omp.h>
 
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,12 +36,16 @@
 #include <thread>
 #include <vector>
 
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "talc_hip.h"
 
 namespace {
 
 struct Options {
-  std::string seqFile, outPrefix = "out", queryMode = "memory", dump, jdump;
+  std::string seqFile, outPrefix = "out", queryMode = "memory", dump, jdump, jf2;
   talc_params p;
   bool haveK = false, haveSR = false, useJ = false;
   int gpus = -1;
@@ -52,9 +61,10 @@ void usage(FILE* f) {
           "  -o, --output TEXT           prefix of the output files (default: out)\n"
           "  -k, --kmerSize INT          k-mer length, 18..31 (required)\n"
           "  -qm, --query-mode TEXT      memory | jellyfish2 (default: memory)\n"
-          "  -SR, --SRCounts TEXT        short-read k-mer counts, `jellyfish dump -c` text (required)\n"
+          "  -SR, --SRCounts TEXT        short-read k-mer counts: `jellyfish dump -c` text or the .jf itself (required)\n"
           "  -j, --junctions TEXT        k-mers flanking junctions and their counts\n"
-          "  -jf2, --pathToJF2 TEXT      accepted, unused\n"
+          "  -jf2, --pathToJF2 TEXT      directory of the jellyfish program: -qm jellyfish2 then reads the .jf through\n"
+          "                              `jellyfish dump` (without it: the native .jf reader)\n"
           "  --MIN_INNER_SCORE FLOAT     [0.3,0.9] default 0.7\n"
           "  --MIN_BORDER_SCORE FLOAT    [0.5,0.9] default 0.7\n"
           "  --MIN_COUNT INT             >= 2, default 2\n"
@@ -101,7 +111,7 @@ Options parse(int argc, const char** argv) {
     else if (is(a, "qm", "query-mode")) { o.queryMode = need(i); if (o.queryMode != "memory" && o.queryMode != "jellyfish2") parse_error("the given value '" + o.queryMode + "' is not in the list of allowed values [memory, jellyfish2]"); }
     else if (is(a, "SR", "SRCounts")) { o.dump = need(i); o.haveSR = true; }
     else if (is(a, "j", "junctions")) { o.jdump = need(i); o.useJ = true; }
-    else if (is(a, "jf2", "pathToJF2")) need(i);
+    else if (is(a, "jf2", "pathToJF2")) o.jf2 = need(i);
     else if (is(a, "MIN_INNER_SCORE", "MIN_INNER_SCORE")) { o.p.min_inner_score = num(need(i), "MIN_INNER_SCORE"); range(o.p.min_inner_score, 0.3, 0.9, "MIN_INNER_SCORE"); }
     else if (is(a, "MIN_BORDER_SCORE", "MIN_BORDER_SCORE")) { o.p.min_border_score = num(need(i), "MIN_BORDER_SCORE"); range(o.p.min_border_score, 0.5, 0.9, "MIN_BORDER_SCORE"); }
     else if (is(a, "MIN_COUNT", "MIN_COUNT")) { double v = num(need(i), "MIN_COUNT"); range(v, 2, 4e9, "MIN_COUNT"); o.p.min_count = (uint32_t)v; }
@@ -252,6 +262,40 @@ struct Chunk {
   std::vector<int64_t> stats;           // 5 per read (--read-stats)
 };
 
+// a Jellyfish 2 count file starts with nine digits (the header's length) and the header's opening brace (talc_jf.h)
+bool isJfFile(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  char h[10];
+  if (!f.read(h, 10)) return false;
+  for (int i = 0; i < 9; ++i)
+    if (h[i] < '0' || h[i] > '9') return false;
+  return h[9] == '{';
+}
+
+// `DIR/jellyfish dump -c [-L minCount] -o out file.jf` as a child process (no shell): the program the reference's
+// jellyfish2 mode names (io_pathToJF + "/" + "jellyfish", Jellyfish.cpp:340), asked once for the whole table instead of
+// once per look-up.  Runs before anything touches the GPU.
+extern "C" char** environ;
+bool jellyfishDump(const std::string& dir, const std::string& jf, uint32_t minCount, const std::string& out, std::string& why) {
+  const std::string tool = dir + "/jellyfish", lower = std::to_string(minCount);
+  std::vector<const char*> av = {tool.c_str(), "dump", "-c"};
+  if (minCount > 1) { av.push_back("-L"); av.push_back(lower.c_str()); }
+  av.push_back("-o"); av.push_back(out.c_str());
+  av.push_back(jf.c_str());
+  av.push_back(nullptr);
+  pid_t pid = 0;
+  const int rc = posix_spawn(&pid, tool.c_str(), nullptr, nullptr, const_cast<char* const*>(av.data()), environ);
+  if (rc != 0) { why = "cannot run " + tool + ": " + strerror(rc); return false; }
+  int status = 0;
+  while (waitpid(pid, &status, 0) < 0)
+    if (errno != EINTR) { why = "waitpid failed for " + tool; return false; }
+  if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+    why = tool + " dump " + jf + " ended with " + (WIFEXITED(status) ? "exit code " + std::to_string(WEXITSTATUS(status)) : std::string("a signal"));
+    return false;
+  }
+  return true;
+}
+
 double secs(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
   return std::chrono::duration<double>(b - a).count();
 }
@@ -288,9 +332,34 @@ int main(int argc, const char** argv) {
   std::cout << "[TALC]: " << nReadsTotal << " long read(s) loaded" << std::endl;
   auto t1 = std::chrono::steady_clock::now();
 
+  // -qm jellyfish2 (the reference: no table, one `jellyfish query` child per look-up — and never reached):
+  // the same counts as ONE table, from the tool's dump when -jf2 names it, else from the .jf itself; memory mode
+  // takes a .jf too.  A jellyfish2 run with neither keeps the reference's behaviour (below).
+  bool buildTable = (o.queryMode == "memory");
+  std::vector<std::string> tmpFiles;
+  if (o.queryMode == "jellyfish2" && !o.jf2.empty()) {
+    std::string why;
+    const std::string sr = o.outPrefix + ".SRCounts.dump.tmp", jn = o.outPrefix + ".junctions.dump.tmp";
+    std::cout << "[TALC]: jellyfish2 mode: " << o.jf2 << "/jellyfish dump of " << o.dump << std::endl;
+    tmpFiles.push_back(sr);
+    bool ok = jellyfishDump(o.jf2, o.dump, o.p.min_count, sr, why);
+    if (ok && o.useJ) { tmpFiles.push_back(jn); ok = jellyfishDump(o.jf2, o.jdump, 0, jn, why); }
+    if (!ok) {
+      for (const auto& f : tmpFiles) std::remove(f.c_str());
+      std::cerr << "talc: " << why << "\n";
+      return 2;
+    }
+    o.dump = sr;
+    if (o.useJ) o.jdump = jn;
+    buildTable = true;
+  } else if (o.queryMode == "jellyfish2" && isJfFile(o.dump)) {
+    std::cout << "[TALC]: jellyfish2 mode: reading " << o.dump << " natively" << std::endl;
+    buildTable = true;
+  }
+
   talc_table* table = nullptr;
   uint64_t tableSize = 0;
-  if (o.queryMode == "memory") {  // main.cpp:224-238
+  if (buildTable) {  // main.cpp:224-238
     if (o.useJ) std::cout << "[TALC]: Building the SR-cdBG from count files: " << o.dump << " and " << o.jdump << std::endl;
     else std::cout << "[TALC]: Building the SR-dBG from count file: " << o.dump << std::endl;
     int64_t st[3] = {0, 0, 0};
@@ -298,6 +367,7 @@ int main(int argc, const char** argv) {
     int rc = (talc_device_count() > 0)
                  ? talc_table_build_device(o.dump.c_str(), o.useJ ? o.jdump.c_str() : nullptr, &o.p, 0, &table, st)
                  : talc_table_build(o.dump.c_str(), o.useJ ? o.jdump.c_str() : nullptr, &o.p, &table, st);
+    for (const auto& f : tmpFiles) std::remove(f.c_str());
     if (rc != TALC_OK) {
       // an unreadable dump leaves the reference with an empty map (Jellyfish.cpp:249-251); anything else is fatal
       std::cerr << "talc: " << talc_last_error() << "\n";
@@ -311,8 +381,9 @@ int main(int argc, const char** argv) {
   }
   auto t2 = std::chrono::steady_clock::now();
   // main.cpp:240: with -qm jellyfish2 the reference runs the loop on an EMPTY map (the jellyfish2 code
-  // path is dead): every read longer than K logs "No solid kmer could be found."
-  const bool emptyRun = (o.queryMode == "jellyfish2");
+  // path is dead): every read longer than K logs "No solid kmer could be found."  Kept when the run names
+  // neither the jellyfish program nor a .jf file.
+  const bool emptyRun = !buildTable;
   if (!emptyRun && tableSize == 0) {
     std::cout << "[TALC]: The de Bruijn Graph is empty...Correction aborted." << std::endl;  // main.cpp:319-320
     return 1;

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "talc_common.h"
+#include "talc_jf.h"
 
 namespace talc {
 
@@ -200,8 +201,11 @@ static inline bool packText(const char* s, size_t len, uint32_t K, uint64_t& out
 // counted as bad; kept k-mers that are not K letters of ACGT are not representable and dropped.
 // wantCounts false: the second token is returned as a signed count for every line (junction dumps).
 struct DumpStats { int64_t nread = 0, nkept = 0, nbad = 0; };
+// A file that starts with a Jellyfish 2 header is read as that tool's binary count file (talc_jf.h) under the same
+// contract; what does not verify there returns false with *err set (a file that cannot be opened leaves *err empty).
 static inline bool parseDumpFile(const char* path, uint32_t K, uint32_t minc, bool filter, std::vector<uint64_t>& kmers,
-                                 std::vector<uint32_t>* counts, std::vector<int64_t>* scounts, DumpStats& st) {
+                                 std::vector<uint32_t>* counts, std::vector<int64_t>* scounts, DumpStats& st,
+                                 std::string* err = nullptr) {
   const int fd = open(path, O_RDONLY);
   if (fd < 0) return false;
   struct stat sb;
@@ -211,6 +215,15 @@ static inline bool parseDumpFile(const char* path, uint32_t K, uint32_t minc, bo
   const char* base = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
   if (base == MAP_FAILED) return false;
+  if (jfLooksLike(base, size)) {
+    JfStats js;
+    std::string why;
+    const bool ok = jfParseImage(base, size, K, minc, filter, kmers, counts, scounts, js, why);
+    munmap((void*)base, size);
+    if (!ok && err) *err = std::string(path) + ": " + why;
+    st.nread += js.nread; st.nkept += js.nkept;
+    return ok;
+  }
   int T = omp_get_max_threads();
   if (T > 64) T = 64;
   if (size < (1u << 20)) T = 1;

@@ -155,3 +155,88 @@ def test_cli_end_to_end_files_identical_to_reference_driver(cli, data, tmp_path,
         assert len(rows) >= 55 and all(len(r.split(b"\t")) == 5 for r in rows)
     lines = fa[".fa"].splitlines()
     assert len([l for l in lines if l.startswith(b">")]) == 60 and max(len(l) for l in lines if not l.startswith(b">")) == 70
+
+
+# ---------------------------------------------------------------- jellyfish2 query mode / .jf input
+FAKE_JELLYFISH = """#!/usr/bin/env python3
+# stand-in for `jellyfish dump -c [-L n] -o OUT FILE.jf` (test only): the text dump kept next to FILE.jf, filtered by -L
+import os, sys
+a = sys.argv[1:]
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "calls.log"), "a").write(" ".join(a) + "\\n")
+if os.environ.get("FAKE_JELLYFISH_EXIT"):
+    sys.exit(int(os.environ["FAKE_JELLYFISH_EXIT"]))
+assert a[0] == "dump" and "-c" in a and "-o" in a, a
+low = int(a[a.index("-L") + 1]) if "-L" in a else 0
+with open(a[-1] + ".txt") as f, open(a[a.index("-o") + 1], "w") as g:
+    for line in f:
+        t = line.split()
+        if len(t) >= 2 and int(t[1]) >= low:
+            g.write(line)
+"""
+
+
+@pytest.fixture(scope="module")
+def jfdata(data, tmp_path_factory):
+    """sr.jf / junc.jf in the layout talc_jf.h reads (tests/jf_writer.py), their text dumps next to them under the
+    names the stand-in tool opens, and a directory holding that tool as `jellyfish`."""
+    import shutil
+    import jf_writer as JW
+    d = tmp_path_factory.mktemp("jfcli")
+    JW.dump_to_jf(str(data / "sr.dump"), str(d / "sr.jf"), 21, seed=8)
+    JW.dump_to_jf(str(data / "junc.dump"), str(d / "junc.jf"), 21, seed=9)
+    shutil.copy(data / "sr.dump", d / "sr.jf.txt")
+    shutil.copy(data / "junc.dump", d / "junc.jf.txt")
+    tool = d / "bin"
+    tool.mkdir()
+    (tool / "jellyfish").write_text(FAKE_JELLYFISH)
+    os.chmod(tool / "jellyfish", 0o755)
+    return d
+
+
+def nodes_line(stdout):
+    return [l for l in stdout.splitlines() if b"SR-dBG contains" in l]
+
+
+def test_cli_jellyfish2_mode_builds_the_table_from_the_tool_or_the_jf(cli, data, jfdata, tmp_path):
+    """Up to the table (no GPU needed): -qm jellyfish2 -jf2 DIR runs DIR/jellyfish dump -c -L MIN_COUNT once per file
+    and builds the table of the text dump; without -jf2 the .jf is read natively; the temporary dumps are removed; a
+    failing or missing tool ends the run with exit code 2."""
+    base = [str(data / "reads.fa"), "-k", "21"]
+    want = nodes_line(run(cli, base + ["-SR", str(data / "sr.dump"), "-j", str(data / "junc.dump"), "-o", "m"], tmp_path).stdout)
+    assert len(want) == 1 and not want[0].endswith(b" 0 nodes.")
+    jf = ["-SR", str(jfdata / "sr.jf"), "-j", str(jfdata / "junc.jf")]
+    r = run(cli, base + jf + ["-qm", "jellyfish2", "-jf2", str(jfdata / "bin"), "--MIN_COUNT", "2", "-o", "t"], tmp_path)
+    assert nodes_line(r.stdout) == want, (r.stdout, r.stderr)
+    calls = (jfdata / "bin" / "calls.log").read_text().splitlines()
+    assert calls[-2] == "dump -c -L 2 -o t.SRCounts.dump.tmp " + str(jfdata / "sr.jf")
+    assert calls[-1] == "dump -c -o t.junctions.dump.tmp " + str(jfdata / "junc.jf")
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    r = run(cli, base + jf + ["-qm", "jellyfish2", "-o", "n"], tmp_path)         # native reader
+    assert nodes_line(r.stdout) == want and b"natively" in r.stdout, (r.stdout, r.stderr)
+    r = run(cli, base + jf + ["-o", "mm"], tmp_path)                             # memory mode takes a .jf too
+    assert nodes_line(r.stdout) == want, (r.stdout, r.stderr)
+    env = dict(os.environ, FAKE_JELLYFISH_EXIT="3")
+    r = subprocess.run([cli] + base + jf + ["-qm", "jellyfish2", "-jf2", str(jfdata / "bin"), "-o", "f"], cwd=tmp_path, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2 and b"ended with exit code 3" in r.stderr
+    r = run(cli, base + jf + ["-qm", "jellyfish2", "-jf2", str(tmp_path / "nowhere"), "-o", "g"], tmp_path)
+    assert r.returncode == 2 and b"cannot run" in r.stderr
+    r = run(cli, base + ["-SR", str(jfdata / "sr.jf"), "-k", "25", "-o", "k"], tmp_path)   # -k disagrees with the file
+    assert r.returncode == 2 and b"21-mers" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_jellyfish2_mode_end_to_end_equals_the_memory_mode_run(cli, data, jfdata, tmp_path):
+    """The three routes to the counts of a .jf give the records and the log of the memory-mode run on its text dump
+    (which test_cli_end_to_end_files_identical_to_reference_driver ties to the reference driver)."""
+    base = [str(data / "reads.fa"), "-k", "21"]
+    m = run(cli, base + ["-SR", str(data / "sr.dump"), "-j", str(data / "junc.dump"), "-o", "m"], tmp_path)
+    assert m.returncode == 0, m.stderr.decode()
+    want = files(str(tmp_path / "m"))
+    assert want[".log"] is not None and b"No solid kmer" not in want[".log"].split(b"\n")[0]
+    jf = ["-SR", str(jfdata / "sr.jf"), "-j", str(jfdata / "junc.jf")]
+    for name, extra in (("tool", ["-qm", "jellyfish2", "-jf2", str(jfdata / "bin")]), ("native", ["-qm", "jellyfish2"]), ("mem", [])):
+        r = run(cli, base + jf + extra + ["-o", name], tmp_path)
+        assert r.returncode == 0, (name, r.stderr.decode())
+        got = files(str(tmp_path / name))
+        assert got[".fa"] == want[".fa"] and got[".log"] == want[".log"], name
