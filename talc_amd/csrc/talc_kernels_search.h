@@ -44,6 +44,11 @@ struct ReadState {
   uint32_t overflow;    // OVF_* bits: scratch exhausted, read left unchanged
   uint32_t inSpan;      // sum over the IN regions of (end - start + 1), as they stand (Read.cpp:423: the stats row)
   uint32_t costEst;     // k_structure's estimate of the search's work (orders the work queue: heaviest reads first)
+#ifdef TALC_PROF
+  // profile build only (TALC_PROF_READS=file writes one row per read): the estimate's inputs and what the search took
+  uint32_t pfHead, pfTail, pfGapSum, pfFork, pfSolid, pfTicks;   // pfTicks: 100 MHz
+  uint32_t pfGapSq, pfGapMax, pfShortReg, pfSteps;
+#endif
 };
 
 __host__ __device__ inline uint64_t out_capacity_for(uint64_t L) { return 4 * L + 1024; }
@@ -314,6 +319,14 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   uint32_t vmax = 0;
   for (uint32_t i = l; i < n; i += 64) { const uint32_t x = cov[i].x; if (x >= MINC) { m += 1; vmax = max(vmax, x); } }
   m = wave_sum_u64(m);
+#ifdef TALC_PROF
+  unsigned long long nFork = 0;   // solid k-mers with more than one successor or predecessor in the graph (per-read rows)
+  for (uint32_t i = l; i < n; i += 64) {
+    const uint2 c = cov[i];
+    nFork += ((c.x >= MINC) && (c.y & kCovDegKnown) && ((((c.y >> kCovDegRShift) & 7u) > 1u) || (((c.y >> kCovDegLShift) & 7u) > 1u))) ? 1u : 0u;
+  }
+  nFork = wave_sum_u64(nFork);
+#endif
   vmax = wave_max_u32(vmax);
   uint32_t first = 0, last = (uint32_t)m;
   if (m > 10) { first = (uint32_t)(0.15 * (double)m); last = (uint32_t)(0.90 * (double)m); }
@@ -474,6 +487,20 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     if (head > 0 && head <= P.MAX_BORDER_LEN) cost += (unsigned long long)P.costEdgeLin * head + (unsigned long long)P.costEdgeQuad * head * head;
     if (tail > 0 && tail <= P.MAX_BORDER_LEN) cost += (unsigned long long)P.costEdgeLin * tail + (unsigned long long)P.costEdgeQuad * tail * tail;
     cost += 50ull * (unsigned long long)L;
+#ifdef TALC_PROF
+    {
+      unsigned long long gs = 0;
+      for (uint32_t i = l; i + 1 < Rfinal; i += 64) gs += (regS[i + 1] > regE[i] + K) ? (unsigned long long)(regS[i + 1] - (regE[i] + K)) : 0ull;
+      st.pfGapSum = (uint32_t)wave_sum_u64(gs);
+      unsigned long long g2 = 0, sr = 0; uint32_t gm = 0;
+      for (uint32_t i = l; i < Rfinal; i += 64) {
+        const unsigned long long g = (i + 1 < Rfinal && regS[i + 1] > regE[i] + K) ? (unsigned long long)(regS[i + 1] - (regE[i] + K)) : 0ull;
+        g2 += g * g; gm = max(gm, (uint32_t)g); sr += (regE[i] - regS[i] < 2u) ? 1u : 0u;
+      }
+      st.pfGapSq = (uint32_t)min(wave_sum_u64(g2), 0xFFFFFFFFull); st.pfGapMax = wave_max_u32(gm); st.pfShortReg = (uint32_t)wave_sum_u64(sr); st.pfSteps = 0;
+      st.pfHead = (uint32_t)head; st.pfTail = (uint32_t)tail; st.pfFork = (uint32_t)nFork; st.pfSolid = (uint32_t)m; st.pfTicks = 0;
+    }
+#endif
     cost >>= 6;   // (fits 32 bits for any read)
     st.costEst = (uint32_t)min(cost, 0xFFFFFFFFull);
   }
@@ -2511,6 +2538,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       const int bk = dt < 25000ull ? 0 : dt < 100000ull ? 1 : dt < 400000ull ? 2 : dt < 1600000ull ? 3 : dt < 6400000ull ? 4 : 5;
       g_prof[PF_RD0 + bk] += 1;
       if (dt > g_prof[PF_RDMAX]) g_prof[PF_RDMAX] = (uint32_t)dt;
+      state[_pf_prevR].pfTicks = (uint32_t)dt;
     }
     _pf_rd0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -2614,6 +2642,9 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       }
     }
     totCells += X.cells; totSteps += X.steps;
+#ifdef TALC_PROF
+    if (l == 0) state[r].pfSteps = (uint32_t)X.steps;
+#endif
     if (X.overflow) {
       wave_copy_bytes(out, X.read, L, false);
       if (l == 0) { state[r].outLen = L; state[r].overflow = X.overflow; }
@@ -2679,6 +2710,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       atomicMin((unsigned long long*)&counters[62], _pf_r0);
       atomicMax((unsigned long long*)&counters[63], r1);
       // the wave's last read: (queue position, read), (its start, the wave's end) — TALC_PROF_SLOW prints the waves that end last
+      if (_pf_rd0) state[_pf_prevR].pfTicks = (uint32_t)(r1 - _pf_rd0);
       if (blockIdx.x < 8192u) {
         counters[64 + 2 * blockIdx.x] = ((unsigned long long)_pf_prevQi << 32) | _pf_prevR;
         counters[65 + 2 * blockIdx.x] = ((_pf_rd0 & 0xFFFFFFFFull) << 32) | (r1 & 0xFFFFFFFFull);
