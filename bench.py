@@ -83,7 +83,7 @@ def resolve_workload(a, world):
 
 def build_table(T, synth, w, params, dev, rank, world, dist, torch, log):
     """Rank 0 builds the table on its GPU (insertion, colouring, de-colouring: all kernels); for N > 1 its device
-    image goes to every other rank by one RCCL broadcast per bucket table and is imported there."""
+    image goes to every other rank by RCCL broadcasts (1 GiB pieces of the two bucket tables) and is imported there."""
     n_dump = 0
     table = None
     if rank == 0:
@@ -107,8 +107,9 @@ def build_table(T, synth, w, params, dev, rank, world, dist, torch, log):
         bl = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
         if rank == 0:
             table.export_device(dev, br.data_ptr(), bl.data_ptr())
-        dist.broadcast(br, src=0)
-        dist.broadcast(bl, src=0)
+        for buf in (br, bl):      # pieces of 1 GiB: element counts stay far below any 32-bit limit on the way
+            for lo in range(0, buf.numel(), 1 << 30):
+                dist.broadcast(buf[lo:lo + (1 << 30)], src=0)
         torch.cuda.synchronize()
         if rank != 0:
             table = T.Table.import_device(params, cap, nk, br.data_ptr(), bl.data_ptr(), dev)
