@@ -81,6 +81,12 @@ def resolve_workload(a, world):
     return w
 
 
+def rehearsal():
+    """TALC_BENCH_REHEARSAL=1: the N > 1 code path on a box with ONE GPU — every rank on device 0, backend gloo, collectives
+    staged through host memory.  For checking the path's logic only; its numbers mean nothing and the line says so."""
+    return os.environ.get("TALC_BENCH_REHEARSAL", "") == "1"
+
+
 def build_table(T, synth, w, params, dev, rank, world, dist, torch, log):
     """Rank 0 builds the table on its GPU (insertion, colouring, de-colouring: all kernels); for N > 1 its device
     image goes to every other rank by RCCL broadcasts (1 GiB pieces of the two bucket tables) and is imported there."""
@@ -97,7 +103,7 @@ def build_table(T, synth, w, params, dev, rank, world, dist, torch, log):
     else:
         keys = counts = None
     if world > 1:
-        meta = torch.zeros(3, dtype=torch.int64, device="cuda")
+        meta = torch.zeros(3, dtype=torch.int64, device="cpu" if rehearsal() else "cuda")
         if rank == 0:
             meta[0], meta[1], meta[2] = table.capacity, len(table), n_dump
         dist.broadcast(meta, src=0)
@@ -109,7 +115,13 @@ def build_table(T, synth, w, params, dev, rank, world, dist, torch, log):
             table.export_device(dev, br.data_ptr(), bl.data_ptr())
         for buf in (br, bl):      # pieces of 1 GiB: element counts stay far below any 32-bit limit on the way
             for lo in range(0, buf.numel(), 1 << 30):
-                dist.broadcast(buf[lo:lo + (1 << 30)], src=0)
+                piece = buf[lo:lo + (1 << 30)]
+                if rehearsal():
+                    host = piece.cpu()
+                    dist.broadcast(host, src=0)
+                    piece.copy_(host)
+                else:
+                    dist.broadcast(piece, src=0)
         torch.cuda.synchronize()
         if rank != 0:
             table = T.Table.import_device(params, cap, nk, br.data_ptr(), bl.data_ptr(), dev)
@@ -129,8 +141,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal():
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
 
@@ -167,7 +183,8 @@ def main():
         if world == 1:
             return buf
         # [n][offsets][status][records] per rank, assembled on the device; rank 0 receives them in rank order
-        return SH.gather_records(SH.pack_records_device(torch, buf[:nbytes], oo_, st_), dist, rank, world, dst=0)
+        payload = SH.pack_records_device(torch, buf[:nbytes], oo_, st_)
+        return SH.gather_records(payload.cpu() if rehearsal() else payload, dist, rank, world, dst=0)
 
     def one_step():
         batch.correct()
@@ -194,10 +211,10 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal() else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tb = torch.tensor([float(n_bases)], dtype=torch.float64, device="cuda")
+        tb = torch.tensor([float(n_bases)], dtype=torch.float64, device="cpu" if rehearsal() else "cuda")
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         total_bases = float(tb.item())
     else:
@@ -236,7 +253,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" if not (world > 1 and rehearsal()) else "synthetic; REHEARSAL of the N > 1 path on one GPU over gloo: not a measurement",
             "config": {
                 "workload": w["label"],
                 "baseline_config": w["config"], "reads_total": w["reads"], "reads_rank0": n_mine, "k": w["k"],
