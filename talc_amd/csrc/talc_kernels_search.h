@@ -1572,7 +1572,7 @@ TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_)
   }
 }
 
-TALC_DN int step_bridge(int nCur, int len, uint32_t& stepCounter) {
+TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   PROF_DECL;
   const DevParams& P = X.P;
   const int l = lane_id();
@@ -1730,7 +1730,7 @@ TALC_DN int score_edges(int ib_, int n_, int len_, int& xdrop_) {
 }
 
 // Explorer::oneMoreStepInTheDark (Explorer.cpp:615-687)
-TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, int& xdrop) {
+TALC_D int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, int& xdrop) {
   PROF_DECL;
   const DevParams& P = X.P;
   const int l = lane_id();
@@ -2247,7 +2247,7 @@ TALC_D AnchorRec uni_anchor(const AnchorRec* p) {
 }
 
 // Explorer::searchBridge (Explorer.cpp:868-989) after initializeINNER(…, direction)
-TALC_DN bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
   PROF_DECL; PROF_DECL2;
   const DevParams& P = X.P;
   const uint32_t K = (uint32_t)uni((int)P.K);
