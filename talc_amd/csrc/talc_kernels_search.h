@@ -1254,7 +1254,7 @@ TALC_DN bool seed_and_extension_multi(const uint8_t* ref, int refLen, const uint
 // Trail's record is read again after the extension instead of being held across it, so that this function keeps no
 // vector register alive over the call — a vector register held over a call has to be a callee-saved one, and every
 // callee-saved register a function touches costs a scratch store and a load per call of it.)
-TALC_DN bool trail_seed_and_extend(int set_, int t_, int len_, int xdrop_) {
+TALC_D bool trail_seed_and_extend(int set_, int t_, int len_, int xdrop_) {
   const int set = uni(set_), t = uni(t_), len = uni(len_), xdrop = uni(xdrop_);
   WSYNC();   // the Trail's last bases were appended by lane 0: make them visible to the DP lanes
   const uint32_t buf = (uint32_t)uni((int)tr_buf(set, t));
@@ -1678,7 +1678,7 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
 // Explorer::scoreEdges (Explorer.cpp:709-740) on the new set (n trails of length len); survivors
 // are compacted in place; returns their number
 // (ib = the Trail set to score: the new set of a generic step, or the current set when the fast-forward took the step)
-TALC_DN int score_edges(int ib_, int n_, int len_, int& xdrop_) {
+TALC_D int score_edges(int ib_, int n_, int len_, int& xdrop_) {
   const int n = uni(n_), len = uni(len_);
   if (n == 0) return 0;
   const int l = lane_id();
