@@ -98,8 +98,19 @@ struct talc_ctx {
   // a batch per chunk of reads: ~20 hipMalloc / hipFree pairs each time otherwise)
   std::vector<std::pair<uint64_t, void*>> pool;   // (bytes, pointer), free
   std::map<void*, uint64_t> live;                 // pointer -> bytes, handed out
-  uint64_t pool_bytes = 0;
+  uint64_t pool_bytes = 0;        // bytes cached (free)
+  uint64_t live_bytes = 0;        // bytes handed out
+  uint64_t peak_live_bytes = 0;   // the largest footprint the batches of this context have had together
 };
+
+// drop cached buffers, oldest first, until the cache holds at most `keep_bytes`
+static void ctx_pool_trim(talc_ctx* c, uint64_t keep_bytes) {
+  while (!c->pool.empty() && c->pool_bytes > keep_bytes) {
+    c->pool_bytes -= c->pool.front().first;
+    hipFree(c->pool.front().second);
+    c->pool.erase(c->pool.begin());
+  }
+}
 
 // a device buffer of at least `bytes` from the context's cache (smallest cached one that fits and is not more than
 // twice as large), or a fresh one
@@ -111,6 +122,8 @@ static int ctx_alloc(talc_ctx* c, void** out, uint64_t bytes) {
   if (best >= 0) {
     *out = c->pool[best].second;
     c->live[*out] = c->pool[best].first;
+    c->live_bytes += c->pool[best].first;
+    c->peak_live_bytes = std::max(c->peak_live_bytes, c->live_bytes);
     c->pool_bytes -= c->pool[best].first;
     c->pool.erase(c->pool.begin() + best);
     return TALC_OK;
@@ -118,25 +131,34 @@ static int ctx_alloc(talc_ctx* c, void** out, uint64_t bytes) {
   if (hipMalloc(out, bytes) != hipSuccess) {
     // out of memory: drop the cache and try once more
     (void)hipGetLastError();
-    for (auto& e : c->pool) hipFree(e.second);
-    c->pool.clear(); c->pool_bytes = 0;
+    ctx_pool_trim(c, 0);
     HIPCHK(hipMalloc(out, bytes));
   }
   c->live[*out] = bytes;
+  c->live_bytes += bytes;
+  c->peak_live_bytes = std::max(c->peak_live_bytes, c->live_bytes);
   return TALC_OK;
 }
 static void ctx_release(talc_ctx* c, void* p) {
   if (!p) return;
   auto it = c->live.find(p);
   if (it == c->live.end()) { hipFree(p); return; }
-  c->pool.push_back({it->second, p});
-  c->pool_bytes += it->second;
+  const uint64_t bytes = it->second;
   c->live.erase(it);
-  while (c->pool.size() > 64) {   // a bounded cache: drop the oldest entries beyond 64 buffers
+  c->live_bytes -= bytes;
+  c->pool.push_back({bytes, p});
+  c->pool_bytes += bytes;
+  // a bounded cache, by count and by bytes: what one batch hands back is what the next one of the same shape asks for, so
+  // cache + live buffers never need to exceed the largest footprint the batches of this context have had (everybody
+  // else who sizes something from hipMemGetInfo — the search scratch, the retry stage, another context on the same GPU,
+  // the walk-table decision of an upload — sees cached bytes as used)
+  while (c->pool.size() > 64) {
     c->pool_bytes -= c->pool.front().first;
     hipFree(c->pool.front().second);
     c->pool.erase(c->pool.begin());
   }
+  if (c->pool_bytes + c->live_bytes > c->peak_live_bytes)
+    ctx_pool_trim(c, c->peak_live_bytes > c->live_bytes ? c->peak_live_bytes - c->live_bytes : 0);
 }
 
 struct talc_batch {
@@ -383,23 +405,43 @@ int talc_table_decolour_repeats(talc_table* t) {
   return TALC_OK;
 }
 uint64_t talc_table_size(const talc_table* t) { return t ? t->h.nkmers : 0; }
+// bits per k-mer of the presence filter (config 2: 10 bits 2.64 ms, 14 2.49, 20 2.39, 28 2.34 for k_coverage; TALC_FILTER_BITS: experiments)
+static uint64_t filter_words_for(uint64_t nkmers) {
+  uint64_t bitsPerKmer = 20;
+  if (const char* e = getenv("TALC_FILTER_BITS")) bitsPerKmer = std::min<uint64_t>(64, std::max<uint64_t>(4, strtoull(e, nullptr, 10)));
+  return (std::max<uint64_t>(64, (nkmers * bitsPerKmer + 63) / 64) + 7) & ~7ull;   // whole 64-byte blocks
+}
+// device bytes of one uploaded copy (what talc_table_upload allocated), or — before any upload — of the copy an upload
+// would make without the walk tables (whether those are built is decided then, from the free memory)
 uint64_t talc_table_device_bytes(const talc_table* t) {
   if (!t) return 0;
-  uint64_t b = 2 * t->h.capacity * sizeof(Bucket) + ((std::max<uint64_t>(64, (t->h.nkmers * 10 + 63) / 64) + 7) & ~7ull) * 8;
-  for (const auto& kv : t->h.dev)   // walk tables, where an upload built them
-    if (kv.second.walkRight) { b += 2 * t->h.capacity * sizeof(WalkEntry); break; }
-  return b;
+  if (!t->h.dev.empty()) {
+    const DeviceCopy& dc = t->h.dev.begin()->second;
+    return 2 * t->h.capacity * sizeof(Bucket) + dc.filterWords * 8 + (dc.walkRight ? 2 * t->h.capacity * sizeof(WalkEntry) : 0);
+  }
+  return 2 * t->h.capacity * sizeof(Bucket) + filter_words_for(t->h.nkmers) * 8;
 }
 
 int talc_table_upload(talc_table* t, int device) {
   if (!t) return fail(TALC_ERR_INVALID, "null table");
   if (t->h.dev.count(device)) return TALC_OK;
-  DeviceCopy dc;
   const uint64_t bytes = t->h.capacity * sizeof(Bucket);
-  if (t->stagedDev == device) {   // built (or imported) on this GPU: the image is adopted as it stands
+  const bool adopt = (t->stagedDev == device);
+  // everything this call allocates is freed again when a later step fails; an adopted image stays the table's staged one
+  // until the copy is complete (a failed upload leaves the table as it was)
+  struct Guard {
+    DeviceCopy dc; bool adopted = false, done = false;
+    ~Guard() {
+      if (done) return;
+      if (!adopted) { hipFree(dc.right); hipFree(dc.left); }
+      hipFree(dc.filter); hipFree(dc.walkRight); hipFree(dc.walkLeft);
+    }
+  } g;
+  DeviceCopy& dc = g.dc;
+  g.adopted = adopt;
+  if (adopt) {   // built (or imported) on this GPU: the image is adopted as it stands
     HIPCHK(hipSetDevice(device));
     dc.right = t->stR; dc.left = t->stL;
-    t->stR = t->stL = nullptr; t->stagedDev = -1;
   } else {
     int rc = ensure_host(t);
     if (rc) return rc;
@@ -410,9 +452,7 @@ int talc_table_upload(talc_table* t, int device) {
     HIPCHK(hipMemcpy(dc.left, t->h.left, bytes, hipMemcpyHostToDevice));
   }
   {   // presence filter, from the RIGHT table
-    uint64_t bitsPerKmer = 20;   // (config 2: 10 bits 2.64 ms, 14 2.49, 20 2.39, 28 2.34 for k_coverage)
-    if (const char* e = getenv("TALC_FILTER_BITS")) bitsPerKmer = std::min<uint64_t>(64, std::max<uint64_t>(4, strtoull(e, nullptr, 10)));   // (experiments)
-    dc.filterWords = (std::max<uint64_t>(64, (t->h.nkmers * bitsPerKmer + 63) / 64) + 7) & ~7ull;   // whole 64-byte blocks
+    dc.filterWords = filter_words_for(t->h.nkmers);
     HIPCHK(hipMalloc((void**)&dc.filter, dc.filterWords * 8));
     HIPCHK(hipMemset(dc.filter, 0, dc.filterWords * 8));
     if (t->h.capacity)
@@ -426,12 +466,8 @@ int talc_table_upload(talc_table* t, int device) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
   }
-  // walk tables (WalkEntry, talc_common.h): twice the bucket tables' size again.  Built when they leave the correction
-  // batches and their scratch a reserve (64 GB, or a quarter of the device if that is less).  Measured on config 5
-  // (547 M k-mers: 70 GB of buckets + 141 GB of walk records = 211 GB of the 288): search 187 ms with them against
-  // 228-242 ms with the per-step probes (profiles/r02; an earlier build of this round had measured the opposite, before
-  // the 8192-bit cycle filter — a record is cut at every false alarm — and kept them below 96 GB only).
-  // TALC_WALK=0 turns them off, TALC_WALK=1 insists.
+  // walk tables (WalkEntry, talc_common.h).  Built when they leave the correction batches and their scratch a reserve
+  // (64 GB, or a quarter of the device if that is less).  TALC_WALK=0 turns them off, TALC_WALK=1 insists.
   {
     const char* env = getenv("TALC_WALK");
     const uint64_t wbytes = t->h.capacity * sizeof(WalkEntry);
@@ -443,7 +479,7 @@ int talc_table_upload(talc_table* t, int device) {
       if (hipMalloc((void**)&dc.walkRight, wbytes) != hipSuccess || hipMalloc((void**)&dc.walkLeft, wbytes) != hipSuccess) {
         (void)hipGetLastError();
         hipFree(dc.walkRight); dc.walkRight = dc.walkLeft = nullptr;
-        if (env) { hipFree(dc.right); hipFree(dc.left); hipFree(dc.filter); return fail(TALC_ERR_NOMEM, "TALC_WALK=1 but the walk tables (%llu bytes) do not fit the device", (unsigned long long)(2 * wbytes)); }
+        if (env) return fail(TALC_ERR_NOMEM, "TALC_WALK=1 but the walk tables (%llu bytes) do not fit the device", (unsigned long long)(2 * wbytes));
       } else {
         const uint64_t nthr = 2 * t->h.capacity;
         hipLaunchKernelGGL(k_build_walk, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, 0, dc.right, dc.left, t->h.capacity,
@@ -454,6 +490,8 @@ int talc_table_upload(talc_table* t, int device) {
     }
   }
   t->h.dev[device] = dc;
+  g.done = true;
+  if (adopt) { t->stR = t->stL = nullptr; t->stagedDev = -1; }
   t->h.frozen = true;
   return TALC_OK;
 }

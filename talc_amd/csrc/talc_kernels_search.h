@@ -2189,6 +2189,10 @@ TALC_D void init_first_trail(const AnchorRec& a, bool withAims, uint32_t pathMax
   pool_reset();
   const uint32_t b0 = (uint32_t)pool_alloc();
   wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
+  // a bridge search's first buffer starts without a kept alignment row.  Every other buffer a search hands out gets its
+  // record from row_copy (branch_copy, garden), so no record is ever read that this search has not written: the stamps in
+  // a record's end words (row_covered) are a second line of defence, not the guarantee.
+  if (withAims && (uint32_t)uni((int)X.rowAvail) != 0u) row_set_covered(b0, 0u);
   // the search's cycle filter: the wave's 8192 bits of LDS, or — for a Trail that may grow to thousands of k-mers, and
   // when the walk-table form of the fast-forward (the one that can read it) is in use — the wide one in HBM
   uint32_t wm = 0;

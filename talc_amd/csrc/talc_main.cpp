@@ -8,7 +8,7 @@
 //
 // Options = the reference's table (same names, defaults, ranges), plus:
 //   --gpus N         number of GPUs to use (default: all visible)
-//   --batch-reads N  reads per device batch (default 200000)
+//   --batch-reads N  reads per device batch (default: two or more batches per worker — two workers per GPU —, 20000..200000)
 //   --read-stats     append the per-read rows of Read::outputBasicReadStats (Read.cpp:418-433) to <o>.stats_basics.txt
 //                    (the reference has that call commented out, main.cpp:305, and only ever writes the header)
 //   -k accepts 18..31 (the reference stops at 30, main.cpp:115-116; 31 still fits 62 bits)
@@ -51,6 +51,7 @@ struct Options {
   int gpus = -1;
   int nthreads = 1;
   uint32_t batchReads = 200000;
+  bool haveBatchReads = false;
   bool readStats = false;
 };
 
@@ -76,7 +77,7 @@ void usage(FILE* f) {
           "  --DEBUG_MODE TEXT           accepted, unused\n"
           "  -rev, --reverse             reverse-complement the long reads before correction\n"
           "  --gpus INT                  GPUs to use (default: all)\n"
-          "  --batch-reads INT           reads per device batch (default 200000)\n"
+          "  --batch-reads INT           reads per device batch (default: at least two batches per worker, 20000..200000)\n"
           "  --read-stats                append per-read rows to <o>.stats_basics.txt (Read.cpp:418-433)\n"
           "  -h, --help / --version\n");
 }
@@ -123,7 +124,7 @@ Options parse(int argc, const char** argv) {
     else if (is(a, "DEBUG_MODE", "DEBUG_MODE")) need(i);
     else if (is(a, "rev", "reverse")) o.p.reverse = 1;
     else if (a == "--gpus") { o.gpus = (int)num(need(i), "gpus"); range(o.gpus, 1, 64, "gpus"); }
-    else if (a == "--batch-reads") { double v = num(need(i), "batch-reads"); range(v, 1, 4e9, "batch-reads"); o.batchReads = (uint32_t)v; }
+    else if (a == "--batch-reads") { double v = num(need(i), "batch-reads"); range(v, 1, 4e9, "batch-reads"); o.batchReads = (uint32_t)v; o.haveBatchReads = true; }
     else if (a == "--read-stats") o.readStats = true;
     else if (a == "-h" || a == "--help") { usage(stdout); exit(0); }
     else if (a == "--version") { std::cout << "talc version: 1.01\nLast update: September 2019\n"; exit(0); }
@@ -187,6 +188,7 @@ class SeqReader {
     }
   }
   bool ok() const { return ok_; }
+  bool fastq() const { return fastq_; }
   // next record; false at the end of the file (or on a malformed FASTQ header: bad() then says so)
   bool next(std::string& id, std::string& seq) {
     seq.clear();
@@ -296,6 +298,30 @@ bool jellyfishDump(const std::string& dir, const std::string& jf, uint32_t minCo
   return true;
 }
 
+// number of records of a FASTA file = lines that start with '>' (what SeqReader::next would return one by one), counted
+// over 4 MB blocks without building a string per line; -1: cannot open
+long long countFastaRecords(const std::string& file) {
+  FILE* f = fopen(file.c_str(), "rb");
+  if (!f) return -1;
+  std::vector<char> buf(4u << 20);
+  long long n = 0;
+  bool atLineStart = true;
+  size_t got;
+  while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) {
+    const char* p = buf.data();
+    const char* end = p + got;
+    while (p < end) {
+      if (atLineStart) { if (*p == '>') ++n; atLineStart = false; }
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+      if (!nl) break;
+      p = nl + 1;
+      atLineStart = true;
+    }
+  }
+  fclose(f);
+  return n;
+}
+
 double secs(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
   return std::chrono::duration<double>(b - a).count();
 }
@@ -322,7 +348,12 @@ int main(int argc, const char** argv) {
   {
     SeqReader probe(o.seqFile);
     std::string id, seq;
-    if (probe.ok()) while (probe.next(id, seq)) ++nReadsTotal;
+    if (probe.ok() && !probe.fastq()) {   // FASTA: the records are the lines that start with '>'
+      const long long n = countFastaRecords(o.seqFile);
+      if (n >= 0) nReadsTotal = (uint64_t)n;
+    } else if (probe.ok()) {
+      while (probe.next(id, seq)) ++nReadsTotal;
+    }
     if (!probe.ok()) {  // main.cpp:219,323: prints and falls off main
       std::cout << "[TALC]: ISSUE WITH INPUT FILES" << std::endl;
       return 0;
@@ -391,15 +422,27 @@ int main(int argc, const char** argv) {
   std::cout << "[TALC]: Good news, there are nodes in the de Bruijn Graph." << std::endl;
   std::cout << "[TALC]: Maybe we can try and correct some long reads, then?" << std::endl;
 
-  int ndev = 0;
+  int ndev = 0, nphys = 0;
   if (!emptyRun) {
-    ndev = talc_device_count();
-    if (ndev <= 0) { std::cerr << "talc: no MI355X / HIP device visible; the correction path has no CPU fallback\n"; return 2; }
+    nphys = talc_device_count();
+    if (nphys <= 0) { std::cerr << "talc: no MI355X / HIP device visible; the correction path has no CPU fallback\n"; return 2; }
+    ndev = nphys;
+    // TALC_FAKE_GPUS=n (a rehearsal hook for one-GPU boxes): the sharder runs as if n GPUs were present, logical GPU d on
+    // physical device d mod the real count — the same worker threads, contexts, dealing and ordered merge
+    if (const char* fk = getenv("TALC_FAKE_GPUS")) if (atoi(fk) > 0) ndev = atoi(fk);
     if (o.gpus > 0) ndev = std::min(ndev, o.gpus);
-    std::cout << "[TALC]: correcting on " << ndev << " GPU(s); k-mer table replicated (" << talc_table_device_bytes(table) / 1e9 << " GB each)" << std::endl;
-    for (int d = 0; d < ndev; ++d)
+    for (int d = 0; d < std::min(ndev, nphys); ++d)
       if (talc_table_upload(table, d) != TALC_OK) { std::cerr << "talc: device error: " << talc_last_error() << "\n"; talc_table_destroy(table); return 2; }
+    std::cout << "[TALC]: correcting on " << ndev << " GPU(s); k-mer table replicated (" << talc_table_device_bytes(table) / 1e9 << " GB each)" << std::endl;
+    if (!o.haveBatchReads) {
+      // at least two batches per worker (two workers per GPU) so that every worker's transfers find kernels to hide
+      // under and the last batches end together; not below 20000 reads (a small batch leaves k_search's 5120 waves a
+      // long tail), not above 200000
+      const uint64_t per = (nReadsTotal + (uint64_t)ndev * 4 - 1) / ((uint64_t)ndev * 4);
+      o.batchReads = (uint32_t)std::min<uint64_t>(200000, std::max<uint64_t>(20000, per));
+    }
   }
+  auto t2b = std::chrono::steady_clock::now();
   std::cout << "Specified output file name: " << outFile << std::endl;
   std::ofstream of(outFile, std::ios_base::trunc);
   if (!of) { std::cerr << "ERROR: Could not open the file " << outFile << "\n"; return 2; }
@@ -418,8 +461,12 @@ int main(int argc, const char** argv) {
   std::string failMsg;
   std::atomic<uint64_t> readErrors{0};
   auto setFailed = [&]() { std::lock_guard<std::mutex> g(failMu); if (!failed) failMsg = talc_last_error(); failed = true; };
+  double readBusy = 0, writeBusy = 0;            // under rdMu / wrMu
+  std::atomic<long long> deviceBusyUs{0};        // summed over the workers
   auto readChunk = [&](PinnedBuf& in) -> std::unique_ptr<Chunk> {
     std::lock_guard<std::mutex> g(rdMu);
+    const auto tr0 = std::chrono::steady_clock::now();
+    struct Acc { double& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{readBusy, tr0};
     std::unique_ptr<Chunk> c(new Chunk());
     std::string id, seq;
     in.len = 0;
@@ -435,6 +482,8 @@ int main(int argc, const char** argv) {
   };
   auto writeReady = [&](std::unique_ptr<Chunk> c) {   // io.cpp:50-75 + SeqFileOut FASTA writer, io.cpp:105-111 log lines
     std::lock_guard<std::mutex> g(wrMu);
+    const auto tw0 = std::chrono::steady_clock::now();
+    struct Acc { double& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{writeBusy, tw0};
     finished[c->index] = std::move(c);
     while (!finished.empty() && finished.begin()->first == nextToWrite) {
       Chunk& k = *finished.begin()->second;
@@ -490,6 +539,8 @@ int main(int argc, const char** argv) {
         const uint32_t n = (uint32_t)c->ids.size();
         c->out.resize(n); c->status.assign(n, TALC_READ_SKIPPED_SHORT);
         talc_batch* b = nullptr;
+        const auto td0 = std::chrono::steady_clock::now();
+        struct Acc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~Acc() { a += (long long)(1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } acc{deviceBusyUs, td0};
         if (talc_batch_create(ctx, in.p, c->offsets.data(), n, &b) != TALC_OK) { setFailed(); break; }
         // < 0: a real HIP / argument error stops the run; TALC_WARN_READ_ERRORS (> 0) is a complete batch in which some
         // reads kept their input sequence (status TALC_READ_ERROR -> a .log line), and the run goes on
@@ -511,7 +562,7 @@ int main(int argc, const char** argv) {
   {
     std::vector<std::thread> workers;
     if (emptyRun) workers.emplace_back(worker, -1);
-    else for (int d = 0; d < ndev; ++d) for (int w = 0; w < 2; ++w) workers.emplace_back(worker, d);
+    else for (int d = 0; d < ndev; ++d) for (int w = 0; w < 2; ++w) workers.emplace_back(worker, d % nphys);
     for (auto& w : workers) w.join();
   }
   of.close();
@@ -524,7 +575,15 @@ int main(int argc, const char** argv) {
   if (table) talc_table_destroy(table);
   if (readErrors) std::cerr << "talc: " << readErrors << " read(s) exhausted the device scratch and were written uncorrected (see " << logFile << ")\n";
   std::cout << "[TALC]: Looks like we are done now." << std::endl;
-  fprintf(stderr, "[talc] scan=%.3fs table=%.3fs read+correct+write=%.3fs (%.3g bases/s, %llu batches) total=%.3fs\n", secs(t0, t1),
-          secs(t1, t2), secs(t2, t3), secs(t2, t3) > 0 ? (double)basesTotal / secs(t2, t3) : 0.0, (unsigned long long)nextIndex, secs(t0, t3));
+  // the reference's own split (main.cpp:213-236: loading the reads, building the graph; :311-313: the correction), in
+  // wall-clock seconds instead of CPU minutes.  The correction phase is a pipeline: its three busy times overlap.
+  fprintf(stderr, "[talc] scan=%.3fs table=%.3fs upload=%.3fs read+correct+write=%.3fs (%.3g bases/s, %llu batches of <= %u reads) total=%.3fs\n",
+          secs(t0, t1), secs(t1, t2), secs(t2, t2b), secs(t2b, t3), secs(t2b, t3) > 0 ? (double)basesTotal / secs(t2b, t3) : 0.0,
+          (unsigned long long)nextIndex, o.batchReads, secs(t0, t3));
+  fprintf(stderr, "[talc-timing] {\"scan_s\": %.4f, \"table_parse_build_s\": %.4f, \"upload_s\": %.4f, \"correct_phase_s\": %.4f, "
+                  "\"reader_busy_s\": %.4f, \"device_busy_s_sum_over_workers\": %.4f, \"writer_busy_s\": %.4f, \"total_s\": %.4f, "
+                  "\"reads\": %llu, \"bases\": %llu, \"batches\": %llu, \"batch_reads\": %u, \"gpus\": %d, \"workers\": %d}\n",
+          secs(t0, t1), secs(t1, t2), secs(t2, t2b), secs(t2b, t3), readBusy, (double)deviceBusyUs.load() / 1e6, writeBusy, secs(t0, t3),
+          (unsigned long long)nReadsTotal, (unsigned long long)basesTotal, (unsigned long long)nextIndex, o.batchReads, ndev, emptyRun ? 1 : 2 * ndev);
   return 0;
 }

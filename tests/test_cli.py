@@ -157,6 +157,30 @@ def test_cli_end_to_end_files_identical_to_reference_driver(cli, data, tmp_path,
     assert len([l for l in lines if l.startswith(b">")]) == 60 and max(len(l) for l in lines if not l.startswith(b">")) == 70
 
 
+@pytest.mark.gpu
+def test_cli_two_gpu_sharder_rehearsed_on_one_device_gives_the_one_gpu_files(cli, tmp_path):
+    """The in-process `--gpus N` sharder (main.cpp:247-308 replaced): TALC_FAKE_GPUS=2 runs it as on a two-GPU node —
+    four workers, their own contexts and streams, batches dealt dynamically, records written in input order — with both
+    logical GPUs on device 0.  <o>.fa and <o>.log must be the one-GPU run's, byte for byte, and its timing line says so."""
+    S = Synth(target_kmers=150_000, k=21, seed=77)
+    S.write_dump(str(tmp_path / "sr.dump"))
+    S.write_fasta(str(tmp_path / "reads.fa"), 0, 900)
+    args = [str(tmp_path / "reads.fa"), "-k", "21", "-SR", str(tmp_path / "sr.dump"), "--batch-reads", "37"]
+    one = run(cli, args + ["-o", "one", "--gpus", "1"], tmp_path)
+    assert one.returncode == 0, one.stderr.decode()
+    env = dict(os.environ, TALC_FAKE_GPUS="2")
+    two = subprocess.run([cli] + args + ["-o", "two", "--gpus", "2"], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert two.returncode == 0, two.stderr.decode()
+    assert b'"gpus": 2' in two.stderr and b'"workers": 4' in two.stderr and b'"gpus": 1' in one.stderr
+    assert b"correcting on 2 GPU(s)" in two.stdout
+    f1, f2 = files(str(tmp_path / "one")), files(str(tmp_path / "two"))
+    assert f1[".fa"] == f2[".fa"] and f1[".log"] == f2[".log"]
+    assert f1[".fa"].count(b">") == 900
+    # default batch size: at least two batches per worker
+    dflt = subprocess.run([cli] + args[:-2] + ["-o", "dflt", "--gpus", "2"], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert dflt.returncode == 0 and files(str(tmp_path / "dflt"))[".fa"] == f1[".fa"]
+
+
 # ---------------------------------------------------------------- jellyfish2 query mode / .jf input (SURVEY §8f.4)
 FAKE_JELLYFISH = """#!/usr/bin/env python3
 # stand-in for `jellyfish dump -c [-L n] -o OUT FILE.jf` (test only): the text dump kept next to FILE.jf, filtered by -L

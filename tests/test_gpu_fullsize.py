@@ -1,7 +1,8 @@
 """-m gpu: BASELINE.json configs at FULL size — too big for an exhaustive oracle run, so they are checked through
 size-independent properties plus an oracle spot-check on a random sample of the very same reads:
   config 2   100 k reads (~2 kb), 50 M-entry k=21 dump
-  config 4   1 M reads, 200 M-entry k=21 dump, --junctions (config 3 is the same table without the colours)
+  config 3   1 M reads, 200 M-entry k=21 dump
+  config 4   the same with --junctions (junction colours: the dual-value probe path)
   config 5   k=31, 500 M-entry dump, 100 k reads of 500 b - 20 kb
 Each case prints one line with the table size, whether the walk tables were built, n_retried / n_failed and the
 kernel times, so the GPU log of the round records them."""
@@ -116,6 +117,12 @@ def _fullsize_case(name, n_kmers, n_reads, k, junctions, synth_kw, n_spot, min_c
 
 def test_config2_full_size_properties():
     _fullsize_case("config2", 50_000_000, 100_000, 21, False, {}, 400, 0.97)
+
+
+def test_config3_full_size_one_million_reads():
+    """BASELINE config 3 as it stands: 1 M reads against the 200 M-entry table, no colours (on one GPU here; over N GPUs
+    the same reads are dealt in chunks, bench.py --gpus N)."""
+    _fullsize_case("config3", 200_000_000, 1_000_000, 21, False, {}, 300, 0.97, check_halves=False)
 
 
 def test_config4_full_size_junctions():

@@ -447,6 +447,54 @@ def test_scratch_retry_pass_gives_identical_records(gpu_pair, monkeypatch):
     ctx2.close()
 
 
+def test_retry_stage_that_does_not_fit_is_a_warning_not_an_error(gpu_pair, monkeypatch):
+    """The first pass leaves a valid batch; when the (much larger) retry stage cannot be allocated the flagged reads
+    are passed through with READ_ERROR and the call returns TALC_WARN_READ_ERRORS — never a negative code that would
+    abort a whole run (include/talc_hip.h: talc_batch_correct)."""
+    bases, offs = gpu_pair.reads(7000, 200)
+    ref_out, ref_off, ref_st = gpu_pair.ctx.correct(bases, offs)
+    monkeypatch.setenv("TALC_TEST_TINY_CAPS", "1")
+    monkeypatch.setenv("TALC_TEST_FAIL_RETRY_ALLOC", "1")
+    ctx2 = T.Context(gpu_pair.ttab, gpu_pair.p, 0)
+    b = ctx2.batch(bases, offs)
+    assert b.correct() == T.WARN_READ_ERRORS
+    out, oo, st = b.fetch_corrected()
+    b.close()
+    t = ctx2.timing()
+    assert t.n_retried > 0 and t.n_failed == t.n_retried
+    seqs, got, want = PU.seqs_of(bases, offs), PU.seqs_of(out, oo), PU.seqs_of(ref_out, ref_off)
+    nerr = 0
+    for i in range(len(seqs)):
+        if st[i] == T.READ_ERROR:
+            nerr += 1
+            assert got[i] == seqs[i]                      # passed through unchanged
+        else:
+            assert st[i] == ref_st[i] and got[i] == want[i]   # every other record is the real one
+    assert nerr == t.n_failed
+    ctx2.close()
+
+
+def test_one_context_over_batches_of_changing_shape_on_a_branching_graph():
+    """The kept alignment rows of scoreBridges live in a per-wave arena that is never reset: batches of different
+    longest reads (the scratch slots move) and searches of different reference lengths (the records' stride changes)
+    through ONE context must still give the oracle's records."""
+    pair = PU.Pair(target_kmers=250_000, k=21, seed=77, synth_kw=dict(paralog_frac=0.6, paralog_div=0.04))
+    pair.upload(0)
+    bases, offs = pair.reads(0, 240)
+    seqs = PU.seqs_of(bases, offs)
+    o_out, o_off, o_st = pair.otab.correct_batch(bases, offs, nthreads=8)
+    want = PU.seqs_of(o_out, o_off)
+    order = sorted(range(len(seqs)), key=lambda i: len(seqs[i]))
+    groups = [order[:60], order[180:], order[60:120], order[120:180], order[::3]]   # short, longest, then mixed again
+    for rep in range(2):
+        for g in groups:
+            b, o = pack([seqs[i] for i in g])
+            out, oo, st = pair.ctx.correct(b, o)
+            got = PU.seqs_of(out, oo)
+            for j, i in enumerate(g):
+                assert got[j] == want[i] and int(st[j]) == int(o_st[i]), (rep, i)
+
+
 def test_batch_composition_and_order_do_not_matter(gpu_pair):
     """Reads are independent units (main.cpp:247): one batch, several batches or a permuted batch
     give the same record per read."""
