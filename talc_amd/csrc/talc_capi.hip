@@ -174,11 +174,13 @@ struct talc_batch {
   uint64_t* d_koff = nullptr;
   uint32_t *d_tile_read = nullptr, *d_tile_start = nullptr, *d_chunk_read = nullptr, *d_chunk_start = nullptr;
   uint32_t* d_order = nullptr;
-  uint2* d_cov = nullptr;
+  uint2* d_cov = nullptr;            // hit pairs, packed per tile inside each read's dense slot (talc_common.h: CovWord)
+  CovWord* d_covw = nullptr;         // one word per 64 k-mer positions
   int32_t* d_nin = nullptr;
   // structure + results
   ReadState* d_state = nullptr;
-  uint32_t* d_regions = nullptr;     // 2 x u32 per region slot
+  uint32_t* d_headcov = nullptr;     // 16 x u32 per read: dense counts of its first positions (k_structure -> k_search)
+  uint32_t* d_regions = nullptr;     // 3 x u32 per region slot (start, end, hit index of the start)
   uint64_t* d_regoff = nullptr;      // per-read offset (in regions) into d_regions
   std::vector<uint64_t> h_regoff;
   uint8_t* d_out = nullptr;          // corrected codes, per-read capacity slots
@@ -664,8 +666,8 @@ void talc_batch_destroy(talc_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
   void* ptrs[] = {b->d_raw, b->d_codes, b->d_offsets, b->d_koff, b->d_tile_read, b->d_tile_start, b->d_chunk_read,
-                  b->d_chunk_start, b->d_order, b->d_cov, b->d_nin, b->d_state, b->d_regions, b->d_regoff, b->d_out, b->d_outoff,
-                  b->d_dense, b->d_dense_off};
+                  b->d_chunk_start, b->d_order, b->d_cov, b->d_covw, b->d_nin, b->d_state, b->d_regions, b->d_regoff, b->d_out, b->d_outoff,
+                  b->d_dense, b->d_dense_off, b->d_headcov};
   for (void* p : ptrs) if (p) ctx_release(b->ctx, p);
   delete b;
 }
@@ -718,9 +720,11 @@ int talc_batch_create(talc_ctx* c, const char* bases, const uint64_t* offsets, u
   if ((rc = up(c, &b->d_chunk_start, b->h_chunk_start, s))) return rc;
   if ((rc = up(c, &b->d_order, b->h_order, s))) return rc;
   if ((rc = ctx_alloc(c, (void**)&b->d_cov, std::max<uint64_t>(b->n_kmers, 1) * sizeof(uint2)))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_covw, cov_words_total(b->n_kmers, n_reads) * sizeof(CovWord)))) return rc;
   if ((rc = ctx_alloc(c, (void**)&b->d_nin, std::max<uint32_t>(n_reads, 1) * sizeof(int32_t)))) return rc;
   if ((rc = ctx_alloc(c, (void**)&b->d_state, std::max<uint32_t>(n_reads, 1) * sizeof(ReadState)))) return rc;
-  if ((rc = ctx_alloc(c, (void**)&b->d_regions, std::max<uint64_t>(ro, 1) * 2 * sizeof(uint32_t)))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_headcov, std::max<uint32_t>(n_reads, 1) * (uint64_t)kHeadCov * sizeof(uint32_t)))) return rc;
+  if ((rc = ctx_alloc(c, (void**)&b->d_regions, std::max<uint64_t>(ro, 1) * 3 * sizeof(uint32_t)))) return rc;
   if ((rc = ctx_alloc(c, (void**)&b->d_out, std::max<uint64_t>(oo, 1)))) return rc;
   HIPCHK(hipStreamSynchronize(s));
   *out = b;
@@ -742,7 +746,7 @@ static int launch_coverage(talc_ctx* c, talc_batch* b) {
   HIPCHK(hipMemsetAsync(b->d_nin, 0, std::max<uint32_t>(b->n_reads, 1) * sizeof(int32_t), c->stream));
   if (!b->h_tile_read.empty())
     hipLaunchKernelGGL(k_coverage, dim3((unsigned)b->h_tile_read.size()), dim3(COV_THREADS), 0, c->stream, c->view,
-                       b->d_codes, b->d_offsets, b->d_koff, b->d_tile_read, b->d_tile_start, b->d_cov, b->d_nin,
+                       b->d_codes, b->d_offsets, b->d_koff, b->d_tile_read, b->d_tile_start, b->d_cov, b->d_covw, b->d_nin,
                        c->p.min_count);
   HIPCHK(hipGetLastError());
   b->covered = true;
@@ -771,9 +775,28 @@ int talc_batch_fetch_coverage(talc_ctx* c, talc_batch* b, uint32_t* counts, uint
   if (!b->covered) return fail(TALC_ERR_STATE, "coverage has not been computed for this batch");
   HIPCHK(hipSetDevice(c->device));
   if (b->n_kmers && (counts || jcounts)) {
+    // the dense vector<colouredCount> of Read.cpp:174-195 exists only here: the device keeps the hits and a bitmap
+    // (talc_common.h: CovWord); hipMemcpy on the null stream would not be ordered with the context's stream
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint64_t nw = cov_words_total(b->n_kmers, b->n_reads);
     std::vector<uint2> h(b->n_kmers);
+    std::vector<CovWord> w(nw);
     HIPCHK(hipMemcpy(h.data(), b->d_cov, b->n_kmers * sizeof(uint2), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < b->n_kmers; ++i) { if (counts) counts[i] = h[i].x; if (jcounts) jcounts[i] = h[i].y & kCovColourMask; }
+    HIPCHK(hipMemcpy(w.data(), b->d_covw, nw * sizeof(CovWord), hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < b->n_reads; ++r) {
+      const uint64_t k0 = b->h_koff[r], nk = b->h_koff[r + 1] - k0;
+      const CovWord* rw = w.data() + cov_word_base(k0, r);
+      for (uint64_t p = 0; p < nk; ++p) {
+        const CovWord& cw = rw[p >> 6];
+        uint32_t cx = 0, cy = 0;
+        if ((cw.bits >> (p & 63)) & 1ull) {
+          const uint64_t idx = (p & ~(uint64_t)(TALC_COV_TILE - 1)) + cw.rank + (uint64_t)__builtin_popcountll(cw.bits & ((1ull << (p & 63)) - 1ull));
+          cx = h[k0 + idx].x; cy = h[k0 + idx].y;
+        }
+        if (counts) counts[k0 + p] = cx;
+        if (jcounts) jcounts[k0 + p] = cy & kCovColourMask;
+      }
+    }
   }
   if (kmer_offsets) memcpy(kmer_offsets, b->h_koff.data(), (b->n_reads + 1) * 8);
   if (n_in_kmers && b->n_reads) HIPCHK(hipMemcpy(n_in_kmers, b->d_nin, b->n_reads * 4, hipMemcpyDeviceToHost));

@@ -66,6 +66,26 @@ static const int kKeyDegShift = 61;
 static const uint32_t kCovColourMask = 0xFFFFu, kCovDegKnown = 1u << 22;
 static const int kCovDegRShift = 16, kCovDegLShift = 19;
 
+// The coverage of a read in HBM — the reference's vector<colouredCount> (Read.cpp:174-195), nine tenths of which is
+// (0, 0) on a noisy read — is kept as the HITS only:
+//   * one CovWord per 64 k-mer positions: bit i of `bits` = the k-mer at position 64 w + i is in the table (its count is
+//     then >= MIN_COUNT: nothing below is ever stored, talc_table_host.h / talc_kernels_build.h, and a context only
+//     runs with the table's own MIN_COUNT), `rank` = number of hits of the same TILE (kCovTile positions) before this
+//     word;
+//   * the hits' {count, colour | degrees} pairs, in position order, packed at the START of their tile's stretch of the
+//     read's dense slot (pair i of the tile that starts at position p0 sits at index p0 + i), so the tiles of a read
+//     — one workgroup each in k_coverage — need no offsets from each other.
+// A read's words start at word (koff >> 6) + r of the batch's word array, koff = its first k-mer's index in the batch and
+// r its number in the batch (that is at least the words of all reads before it).  The dense form exists only in
+// talc_batch_fetch_coverage.  What this saves: the kernel the metric names wrote 1.25 GB of zeros per 100 k reads and the
+// structure kernel read them back.
+#ifndef TALC_COV_TILE
+#define TALC_COV_TILE 512
+#endif
+struct __attribute__((aligned(16))) CovWord { uint64_t bits; uint32_t rank; uint32_t pad; };
+TALC_HD uint64_t cov_word_base(uint64_t koff, uint32_t read_index) { return (koff >> 6) + read_index; }
+TALC_HD uint64_t cov_words_total(uint64_t n_kmers, uint32_t n_reads) { return (n_kmers >> 6) + n_reads + 1; }
+
 // Walk table (device only, derived from a finished Bucket table, same capacity and slot order): what a Trail that
 // keeps following its only solid successor will meet over the next WALK_LEVELS steps, in one 64-byte record, so
 // that the single-Trail fast-forward pays one dependent memory access per WALK_LEVELS steps instead of per step.

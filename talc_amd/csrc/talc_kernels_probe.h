@@ -14,6 +14,8 @@ struct BucketRegs {
   uint32_t cnt[4];
   uint32_t jc01, jc23;  // packed u16 pairs
   TALC_D uint32_t jc(int b) const { uint32_t w = (b < 2) ? jc01 : jc23; return (b & 1) ? (w >> 16) : (w & 0xffffu); }
+  // cnt[b] for a lane-dependent b as selects (an indexed read of a register array goes through the private stack)
+  TALC_D uint32_t count_of(int b) const { const uint32_t lo = (b & 1) ? cnt[1] : cnt[0], hi = (b & 1) ? cnt[3] : cnt[2]; return (b & 2) ? hi : lo; }
 };
 
 TALC_D BucketRegs load_bucket(const Bucket* p) {
@@ -51,7 +53,7 @@ TALC_D bool probe_bucket_from(const Bucket* tab, uint64_t cap, uint64_t key, uin
 TALC_D void dev_get_count(const TableView& T, uint64_t kmer, uint32_t& cnt, uint32_t& jc) {
   BucketRegs r;
   cnt = 0; jc = 0;
-  if (probe_bucket(T.right, T.capacity, kmer >> 2, r)) { const int b = (int)(kmer & 3); cnt = r.cnt[b]; jc = r.jc(b); }
+  if (probe_bucket(T.right, T.capacity, kmer >> 2, r)) { const int b = (int)(kmer & 3); cnt = r.count_of(b); jc = r.jc(b); }
 }
 
 // getNextCounts (Jellyfish.cpp:308-321): the 4 successors of `kmer` walking RIGHT
@@ -103,17 +105,20 @@ __global__ void k_encode(const uint8_t* __restrict__ raw, uint8_t* __restrict__ 
 // One block per tile of up to COV_TILE consecutive k-mer positions of ONE read, in two phases:
 //  A. the tile's base window (COV_TILE + K - 1 codes) is staged into LDS as 2-bit packed words (first base most
 //     significant, so a k-mer is one funnel shift away from its table form) plus an N bitmap; thread t takes positions
-//     t, t+256, ...: k-mer, presence-filter test (one 8-byte word of a block its minimizer chooses: lanes share lines), and either an 8-byte
-//     (0, 0) store — coalesced across the wave — or, for the 7-9 % that may be in the table, an entry in an LDS queue;
+//     t, t+256, ...: k-mer, presence-filter test (one 8-byte word of a block its minimizer chooses: lanes share lines);
+//     the 7-9 % that may be in the table go to an LDS queue, the rest leave no trace at all;
 //  B. the queue is worked off with every lane busy: the 32-byte bucket of the k-mer's (K-1)-prefix — the one random HBM
 //     access of a lookup: it holds the count, the k-mer's left degree (key word's top bits) and the right degree of the
-//     position before (published through LDS; cov_count below); the result overwrites the position's (0, 0).  Doing
-//     this inside phase A would run the probe sequence on every iteration of every wave for one lane in twelve.
+//     position before (published through LDS; cov_count below).  The hits set their bit in the tile's 32 bitmap words
+//     (LDS), the words' ranks are a 32-element scan, and every hit's pair goes to its rank at the start of the tile's
+//     stretch (talc_common.h: CovWord): only hits are written, contiguously.
 //  #{count > MIN_COUNT} (Read.cpp:190) is reduced per block and added to the read's counter.
-#define COV_TILE 2048
-#define COV_THREADS 256
-#ifndef TALC_COV_QUEUE
-#define TALC_COV_QUEUE 1   /* 0: probe inside phase A (experiment) */
+#ifndef TALC_COV_EXP
+#define TALC_COV_EXP 0   /* timing experiments (results wrong on purpose): bit 0 = no table traffic, bit 1 = no filter traffic */
+#endif
+#define COV_TILE TALC_COV_TILE
+#ifndef COV_THREADS
+#define COV_THREADS 64   /* one wave per tile of 512 positions: 32 independent tiles per CU, no wave waits at another's barrier (1.66 ms with 256 threads on 2048 positions, 1.37 ms so; config 2) */
 #endif
 
 // The table part of one lookup, for a k-mer that passed the filter: its count and colour, and — for a k-mer of the
@@ -137,7 +142,7 @@ TALC_D void cov_count(const TableView& T, uint64_t kmer, uint32_t min_count, uin
   if (!probe_bucket(T.right, T.capacity, kp, rc)) return;            // no successor of that (K-1)-mer at all
   degPrev = bucket_degree(rc, min_count);
   const int b = (int)(kmer & 3);
-  c = rc.cnt[b]; j = rc.jc(b);
+  c = rc.count_of(b); j = rc.jc(b);
   if (c != 0) dL = (uint32_t)(rc.key >> kKeyDegShift);
 }
 // step 2 (only for c != 0, when the next position did not publish it): the right degree by its own probe
@@ -147,18 +152,11 @@ TALC_D uint32_t cov_right_degree(const TableView& T, uint64_t kmer, uint32_t min
   BucketRegs br;
   return probe_bucket(T.right, T.capacity, kmer & m1, br) ? bucket_degree(br, min_count) : 0u;
 }
-// the unshared form (experiments: TALC_COV_QUEUE = 0)
-TALC_D void cov_probe(const TableView& T, uint64_t kmer, uint32_t min_count, uint32_t& c, uint32_t& j) {
-  uint32_t dL, degPrev;
-  cov_count(T, kmer, min_count, c, j, dL, degPrev);
-  if (c != 0) j |= kCovDegKnown | (cov_right_degree(T, kmer, min_count) << kCovDegRShift) | (dL << kCovDegLShift);
-}
-
 __global__ void __launch_bounds__(COV_THREADS)
 k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
            const uint64_t* __restrict__ koff, const uint32_t* __restrict__ tile_read,
-           const uint32_t* __restrict__ tile_start, uint2* __restrict__ cov, int32_t* __restrict__ n_in,
-           uint32_t min_count) {
+           const uint32_t* __restrict__ tile_start, uint2* __restrict__ cov, CovWord* __restrict__ covWords,
+           int32_t* __restrict__ n_in, uint32_t min_count) {
   __shared__ uint64_t s_pack[(COV_TILE + 64) / 32 + 3];   // base i of the window at bits [63 - 2 (i % 32) - 1, 63 - 2 (i % 32)] of word i / 32
   __shared__ uint64_t s_nmask[(COV_TILE + 64) / 64 + 2];  // bit (i % 64) of word i / 64: base i is N
 #if TALC_FILTER_MINIMIZER
@@ -166,7 +164,9 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
 #endif
   __shared__ uint16_t s_queue[COV_TILE];                  // positions whose k-mer passed the filter
   __shared__ uint8_t s_degR[COV_TILE + 4];                // right degree of the k-mer at a position, published by the next position's lookup (0xFF: not)
-  __shared__ uint32_t s_qn;
+  __shared__ unsigned long long s_bits[COV_TILE / 64];   // the tile's hit bitmap
+  __shared__ uint32_t s_rank[COV_TILE / 64];             // hits of the tile before each word
+  __shared__ uint32_t s_qn, s_anyN;
   __shared__ int s_nin;
   const uint32_t K = T.k;
   const uint32_t r = tile_read[blockIdx.x];
@@ -178,7 +178,10 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   const uint32_t wlen = cnt + K - 1;                  // bases in the window
   const uint8_t TALC_AS1* src = (const uint8_t TALC_AS1*)(codes + rb + p0);
 
-  if (threadIdx.x == 0) { s_nin = 0; s_qn = 0; }
+  if (threadIdx.x == 0) { s_nin = 0; s_qn = 0; s_anyN = 0; }
+  __syncthreads();
+  bool tileHasN = false;
+  if (threadIdx.x < COV_TILE / 64) s_bits[threadIdx.x] = 0ull;
   for (uint32_t i = threadIdx.x; i < (COV_TILE + 4) / 4; i += COV_THREADS) reinterpret_cast<uint32_t*>(s_degR)[i] = 0xFFFFFFFFu;
   // stage: 16 bases -> one u32 of 2-bit codes (first base in the top bits) + 16 N bits, per thread per pass
   {
@@ -210,9 +213,13 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
       }
       pk32[g ^ 1] = w;          // even group = high half of its 64-bit word
       nm16[g] = (uint16_t)nm;
+      tileHasN |= (nm != 0u);
     }
   }
+  // (nearly every tile is free of N: its positions then skip the N-mask reads of both passes)
+  if (__ballot(tileHasN) != 0ull && (threadIdx.x & 63u) == 0u) s_anyN = 1u;
   __syncthreads();
+  const bool anyN = s_anyN != 0u;
 
   // the 64 window bits that start with base q (first base most significant), and the N bits [q, q + 64)
   auto window = [&](uint32_t q) -> uint64_t {
@@ -229,7 +236,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   const uint32_t M = filter_mmer_len(K);
   const uint32_t nmm = wlen - M + 1;
   for (uint32_t q = threadIdx.x; q < nmm; q += COV_THREADS)
-    s_mh[q] = (nbits(q) & ((1ull << M) - 1)) ? 0xFFFFFFFFu : mmer_hash((uint32_t)(window(q) >> (64 - 2 * M)));
+    s_mh[q] = (anyN && (nbits(q) & ((1ull << M) - 1))) ? 0xFFFFFFFFu : mmer_hash((uint32_t)(window(q) >> (64 - 2 * M)));
   __syncthreads();
   const uint32_t nwin = K - M + 1;                   // M-mers per k-mer
 #endif
@@ -248,7 +255,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   for (int it = 0; it < NPASS; ++it) {
     const uint32_t p = (uint32_t)it * COV_THREADS + threadIdx.x;
     fword[it] = 0; fmask[it] = 1;                  // (p beyond the tile or an N in the k-mer: fails the test below)
-    if (p < cnt && (nbits(p) & nkmask) == 0) {     // no N among bases [p, p+K)
+    if (p < cnt && !(anyN && (nbits(p) & nkmask) != 0)) {     // no N among bases [p, p+K)
       fword[it] = ~0ULL;
       if (filter) {
         const uint64_t kmer = window(p) >> kshift;
@@ -261,7 +268,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
 #else
         const uint64_t idx = filter_block(h.x, nBlocks) * 8 + (h.y >> 29);
 #endif
-#if defined(TALC_COV_EXP) && TALC_COV_EXP == 2   /* timing experiment: no filter traffic, the same share of survivors */
+#if (TALC_COV_EXP & 2)   /* timing experiment: no filter traffic, the same share of survivors */
         fword[it] = ((h.x & 15u) == 0u) ? ~0ULL : 0ULL; (void)idx;
 #else
         fword[it] = filter[idx];
@@ -273,12 +280,7 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
   for (int it = 0; it < NPASS; ++it) {
     const uint32_t pb = (uint32_t)it * COV_THREADS;
     if (pb >= cnt) break;
-    const uint32_t p = pb + threadIdx.x;
     const bool maybe = (fword[it] & fmask[it]) == fmask[it];
-    if (p < cnt) {
-#if TALC_COV_QUEUE
-      if (!maybe) out[p] = v2u32{0u, 0u};
-    }
     // queue the survivors: one LDS atomic per wave
     const unsigned long long bal = __ballot(maybe);
     if (bal) {
@@ -286,47 +288,71 @@ k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __res
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&s_qn, (uint32_t)__popcll(bal));
       base = (uint32_t)__shfl((int)base, 0, 64);
-      if (maybe) s_queue[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)p;
+      if (maybe) s_queue[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint16_t)(pb + threadIdx.x);
     }
   }
   __syncthreads();
-  // ---- phase B
+  // ---- phase B.  A thread keeps the results of its (at most NPASS, nearly always one) queue entries in registers until
+  // the tile's ranks are known.
   const uint32_t qn = s_qn;
-  for (uint32_t qb = 0; qb < qn; qb += COV_THREADS) {   // (block-uniform trip count: the barrier inside is reached by all)
-    const uint32_t qi = qb + threadIdx.x;
-    const bool have = qi < qn;
-    uint32_t p = 0, c = 0, j = 0, dL = 0;
-    uint64_t kmer = 0;
-    if (have) {
-      p = s_queue[qi];
-      kmer = window(p) >> kshift;
-#if defined(TALC_COV_EXP) && TALC_COV_EXP == 1   /* timing experiment: no table traffic */
-      (void)dL;
+  uint32_t myP[NPASS], myC[NPASS], myJ[NPASS];
+#pragma unroll
+  for (int it = 0; it < NPASS; ++it) {
+    myP[it] = 0; myC[it] = 0; myJ[it] = 0;
+    const uint32_t qi = (uint32_t)it * COV_THREADS + threadIdx.x;
+    if ((uint32_t)it * COV_THREADS >= qn) break;   // (block-uniform)
+    if (qi < qn) {
+      const uint32_t p = s_queue[qi];
+      const uint64_t kmer = window(p) >> kshift;
+      uint32_t c = 0, j = 0, dL = 0;
+#if (TALC_COV_EXP & 1)   /* timing experiment: no table traffic */
+      (void)dL; (void)kmer;
 #else
       uint32_t degPrev;
       cov_count(T, kmer, min_count, c, j, dL, degPrev);
       if (p > 0) s_degR[p - 1] = (uint8_t)degPrev;
 #endif
-    }
-    __syncthreads();
-    if (have) {
       if (c != 0) {
-        uint32_t dR = s_degR[p];
-        if (dR == 0xFFu) dR = cov_right_degree(T, kmer, min_count);
-        j |= kCovDegKnown | (dR << kCovDegRShift) | (dL << kCovDegLShift);
+        atomicOr(&s_bits[p >> 6], 1ull << (p & 63u));
+        j |= kCovDegKnown | (dL << kCovDegLShift);
       }
-      out[p] = v2u32{c, j};
+      myP[it] = p; myC[it] = c; myJ[it] = j;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {   // ranks: exclusive scan of the 32 words' populations (first wave)
+    const uint32_t w = threadIdx.x;
+    const uint32_t pc = (w < COV_TILE / 64) ? (uint32_t)__popcll(s_bits[w < COV_TILE / 64 ? w : 0]) : 0u;
+    uint32_t incl = pc;
+#pragma unroll
+    for (int off = 1; off < COV_TILE / 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+      if ((int)w >= off) incl += o;
+    }
+    if (w < COV_TILE / 64) s_rank[w] = incl - pc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NPASS; ++it) {
+    if ((uint32_t)it * COV_THREADS >= qn) break;
+    const uint32_t c = myC[it];
+    if (c != 0) {
+      const uint32_t p = myP[it];
+      uint32_t dR = s_degR[p];
+      if (dR == 0xFFu) dR = cov_right_degree(T, window(p) >> kshift, min_count);
+      const uint32_t idx = s_rank[p >> 6] + (uint32_t)__popcll(s_bits[p >> 6] & ((1ull << (p & 63u)) - 1ull));
+      out[idx] = v2u32{c, myJ[it] | (dR << kCovDegRShift)};
       local_in += (c > min_count) ? 1 : 0;
     }
   }
-#else
-      uint32_t c = 0, j = 0;
-      if (maybe) cov_probe(T, window(p) >> kshift, min_count, c, j);
-      out[p] = v2u32{c, j};
-      local_in += (c > min_count) ? 1 : 0;
+  {   // the tile's words of the read's bitmap (every word of the tile, hit or not)
+    const uint32_t nw = (cnt + 63u) >> 6;
+    if (threadIdx.x < nw) {
+      v4u32 TALC_AS1* wout = (v4u32 TALC_AS1*)(covWords + cov_word_base(koff[r], r) + (p0 >> 6));
+      const unsigned long long bw = s_bits[threadIdx.x];
+      wout[threadIdx.x] = v4u32{(uint32_t)bw, (uint32_t)(bw >> 32), s_rank[threadIdx.x], 0u};   // {bits, rank, pad}
     }
   }
-#endif
   // block reduction of local_in
   for (int off = 32; off > 0; off >>= 1) local_in += __shfl_down(local_in, off, 64);
   if ((threadIdx.x & 63) == 0 && local_in) atomicAdd(&s_nin, local_in);

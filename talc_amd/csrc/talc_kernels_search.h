@@ -71,7 +71,7 @@ struct SearchLimits {   // (the part the search itself consults: a copy lives in
 struct SearchCaps : SearchLimits {
   uint64_t slotBytes;
   uint64_t o_setA, o_setB, o_seqPool, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
-      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak, o_wideBloom, o_rowPool;
+      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak, o_wideBloom, o_rowPool, o_regH;
 };
 
 // The cycle filter of a LONG search (a gap of several kb: a Trail of thousands of k-mers saturates the 8192 bits the wave
@@ -163,6 +163,7 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   c.o_weak = take(c.weakPool);
   c.o_wideBloom = take((uint64_t)WIDE_BLOOM_WORDS * 8);
   c.o_rowPool = take((uint64_t)ROW_ARENA_INTS * 4);
+  c.o_regH = take((uint64_t)c.regCap * 4);
   c.slotBytes = align_up(o, 256);
   return c;
 }
@@ -221,30 +222,89 @@ TALC_D int dev_out_degree(const TableView& T, uint32_t MINC, uint64_t kmer, uint
   return d;
 }
 
+// ------------------------------------------------------------------ the coverage of one read (talc_common.h: CovWord)
+struct CovRead {
+  const uint2 TALC_AS1* hits;       // the read's dense slot: the hits of tile t packed from index t * TALC_COV_TILE
+  const CovWord TALC_AS1* words;    // one word per 64 positions
+};
+TALC_D CovRead cov_read(const uint2* covAll, const CovWord* wordsAll, uint64_t koff, uint32_t r) {
+  CovRead c;
+  c.hits = (const uint2 TALC_AS1*)(covAll + koff);
+  c.words = (const CovWord TALC_AS1*)(wordsAll + cov_word_base(koff, r));
+  return c;
+}
+TALC_D CovWord cov_word(const CovRead& cr, uint32_t w) {
+  const v4u32 q = *(const v4u32 TALC_AS1*)(cr.words + w);
+  CovWord cw; cw.bits = ((uint64_t)q.y << 32) | q.x; cw.rank = q.z; cw.pad = 0;
+  return cw;
+}
+// {count, colour | degrees} of the k-mer at position p (per lane or uniform): (0, 0) when it is not in the table
+TALC_D uint2 cov_at(const CovRead& cr, uint32_t p) {
+  const CovWord cw = cov_word(cr, p >> 6);
+  uint2 v = make_uint2(0u, 0u);
+  if ((cw.bits >> (p & 63u)) & 1ull) {
+    const uint32_t idx = (p & ~(uint32_t)(TALC_COV_TILE - 1)) + cw.rank + (uint32_t)__popcll(cw.bits & ((1ull << (p & 63u)) - 1ull));
+    const v2u32 e = *(const v2u32 TALC_AS1*)(cr.hits + idx);
+    v.x = e.x; v.y = e.y;
+  }
+  return v;
+}
+static const uint32_t kRegClean = 1u << 31;   // flag in a region's hit index (k_structure)
+static const int kHeadCov = 16;               // per read: dense counts of its first positions (k_structure -> build_anchors)
+// index (in the read's hit array) of the pair of position p, which must be a hit
+TALC_D uint32_t cov_hit_index(const CovRead& cr, uint32_t p) {
+  const CovWord cw = cov_word(cr, p >> 6);
+  return (p & ~(uint32_t)(TALC_COV_TILE - 1)) + cw.rank + (uint32_t)__popcll(cw.bits & ((1ull << (p & 63u)) - 1ull));
+}
+// ... and of a position p >= rs inside a RUN of hits that starts at rs (a solid region: every position of it is a hit),
+// rsIdx = cov_hit_index(rs): the pairs of a run are consecutive inside a tile, and a tile the run entered from the left
+// holds the run's pairs from its first slot — no word needs reading
+TALC_D uint32_t cov_run_index(uint32_t rs, uint32_t rsIdx, uint32_t p) {
+  return ((p ^ rs) >= (uint32_t)TALC_COV_TILE) ? p : rsIdx + (p - rs);
+}
+// f(count, colourWord) for every hit of the read, lane-strided.  The tiles' hit counts (rank + population of each tile's
+// last word) are fetched 64 tiles at a time, one per lane: one memory round trip for a read of up to 32 k positions, then
+// the tiles' pairs stream.
+template <class F>
+TALC_D void cov_for_hits(const CovRead& cr, uint32_t n, F&& f) {
+  const int l = lane_id();
+  const uint32_t nTiles = (n + (uint32_t)TALC_COV_TILE - 1u) / (uint32_t)TALC_COV_TILE;
+  for (uint32_t tb = 0; tb < nTiles; tb += 64) {
+    const uint32_t t = tb + (uint32_t)l;
+    uint32_t nhMine = 0;
+    if (t < nTiles) {
+      const uint32_t lastW = (min(n, (t + 1u) * (uint32_t)TALC_COV_TILE) - 1u) >> 6;
+      const CovWord cw = cov_word(cr, lastW);
+      nhMine = cw.rank + (uint32_t)__popcll(cw.bits);
+    }
+    const uint32_t cnt = min(64u, nTiles - tb);
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t nh = (uint32_t)lane_get((int)nhMine, (int)j), t0 = (tb + j) * (uint32_t)TALC_COV_TILE;
+      for (uint32_t i = (uint32_t)l; i < nh; i += 64) { const v2u32 e = *(const v2u32 TALC_AS1*)(cr.hits + t0 + i); f(e.x, e.y); }
+    }
+  }
+}
+
 // ==================================================================== k_structure
 // Read::defineStructure2 for one read per wave.
 // S(r) = sum of the r smallest IN counts (order statistics without sorting: the reference's sort only
 // feeds a trimmed sum, Read.cpp:505-512).  Counts below STRUCT_HBINS go through an LDS histogram (one
 // pass over the coverage, then a scan over the bins); larger ones through a bisection on the value.
 constexpr int STRUCT_HBINS = 1024, STRUCT_DEG_CAP = 512;   // (5 KB of LDS per wave: 32 waves per CU)
-TALC_D unsigned long long trimmed_prefix_sum(const uint2* __restrict__ cov, uint32_t n, uint32_t MINC, uint32_t r, uint32_t vmax) {
+TALC_D unsigned long long trimmed_prefix_sum(const CovRead& cov, uint32_t n, uint32_t MINC, uint32_t r, uint32_t vmax) {
   if (r == 0) return 0ull;
-  const int l = lane_id();
   // smallest v with #{x >= MINC, x <= v} >= r
   uint32_t lo = 0, hi = vmax;
   while (lo < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
     unsigned long long cnt = 0;
-    for (uint32_t i = l; i < n; i += 64) { const uint32_t x = cov[i].x; cnt += (x >= MINC && x <= mid) ? 1 : 0; }
+    cov_for_hits(cov, n, [&](uint32_t x, uint32_t) { cnt += (x >= MINC && x <= mid) ? 1 : 0; });
     cnt = wave_sum_u64(cnt);
     if (cnt >= r) hi = mid; else lo = mid + 1;
   }
   const uint32_t v = lo;
   unsigned long long sumLess = 0, cntLess = 0;
-  for (uint32_t i = l; i < n; i += 64) {
-    const uint32_t x = cov[i].x;
-    if (x >= MINC && x < v) { sumLess += x; cntLess += 1; }
-  }
+  cov_for_hits(cov, n, [&](uint32_t x, uint32_t) { if (x >= MINC && x < v) { sumLess += x; cntLess += 1; } });
   sumLess = wave_sum_u64(sumLess);
   cntLess = wave_sum_u64(cntLess);
   return sumLess + ((unsigned long long)r - cntLess) * (unsigned long long)v;
@@ -272,9 +332,10 @@ TALC_D unsigned long long hist_prefix_sum(const uint32_t* hist, unsigned long lo
 
 __global__ void __launch_bounds__(64)
 k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
-            const uint64_t* __restrict__ koff, const uint2* __restrict__ covAll, const int32_t* __restrict__ n_in,
+            const uint64_t* __restrict__ koff, const uint2* __restrict__ covAll, const CovWord* __restrict__ covWords,
+            const int32_t* __restrict__ n_in,
             ReadState* __restrict__ state, uint32_t* __restrict__ regions, const uint64_t* __restrict__ regoff,
-            uint32_t n_reads, TraceBuf trace, uint32_t traceRead) {
+            uint32_t* __restrict__ headCov, uint32_t n_reads, TraceBuf trace, uint32_t traceRead) {
   const uint32_t r = blockIdx.x;
   if (r >= n_reads) return;
   const int l = lane_id();
@@ -286,21 +347,33 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   if (!(L > K)) { st.status = TALC_READ_SKIPPED_SHORT; if (l == 0) state[r] = st; return; }      // main.cpp:262
   if (!(n_in[r] > 0)) { st.status = TALC_READ_NO_SOLID_KMER; if (l == 0) state[r] = st; return; }  // Read.cpp:194
   const uint32_t n = L - K + 1;
-  const uint2* cov = covAll + koff[r];
-  uint32_t* regS = regions + 2 * regoff[r];
+  const CovRead cov = cov_read(covAll, covWords, koff[r], r);
+  uint32_t* regS = regions + 3 * regoff[r];   // per read: starts, ends, hit indices of the starts (kRegClean: below)
   const uint32_t regCap = (uint32_t)(regoff[r + 1] - regoff[r]);
   uint32_t* regE = regS + regCap;
 
   // ---- findINRegions (Read.cpp:440-489): maximal runs of count >= MIN_COUNT (needs n > 1)
   uint32_t R = 0, Rends = 0;
   if (n > 1) {
+    // (a k-mer is IN iff it is in the table: every stored count is >= MIN_COUNT, talc_common.h — so the runs are the runs
+    //  of the hit bitmap, 64 positions per word, the words of one pass fetched one per lane)
+    const uint32_t nW = (n + 63u) >> 6;
+    unsigned long long prevBits = 0ull;
     for (uint32_t base = 0; base < n; base += 64) {
       const uint32_t i = base + l;
-      const bool in = (i < n) && (cov[i].x >= MINC);
-      const bool inPrev = (i > 0) && (i < n) && (cov[i - 1].x >= MINC);
-      const bool inNext = (i + 1 < n) && (cov[i + 1].x >= MINC);
-      const bool isStart = in && !inPrev, isEnd = in && !inNext;
-      const unsigned long long ms = ballot64(isStart), me = ballot64(isEnd);
+      const uint32_t w = base >> 6;
+      unsigned long long bitsW, nextW = 0ull;
+      {
+        // lanes 0 / 1 fetch this word and the next; both are made uniform
+        const uint32_t wi = w + (uint32_t)(l & 1);
+        const unsigned long long mine = (l < 2 && wi < nW) ? cov_word(cov, wi).bits : 0ull;
+        bitsW = ((unsigned long long)(uint32_t)lane_get((int)(uint32_t)(mine >> 32), 0) << 32) | (uint32_t)lane_get((int)(uint32_t)mine, 0);
+        nextW = ((unsigned long long)(uint32_t)lane_get((int)(uint32_t)(mine >> 32), 1) << 32) | (uint32_t)lane_get((int)(uint32_t)mine, 1);
+      }
+      const unsigned long long ms = bitsW & ~((bitsW << 1) | (prevBits >> 63));
+      const unsigned long long me = bitsW & ~((bitsW >> 1) | (nextW << 63));
+      prevBits = bitsW;
+      const bool isStart = ((ms >> l) & 1ull) != 0ull, isEnd = ((me >> l) & 1ull) != 0ull;
       // the k-th start pairs with the k-th end
       const unsigned long long below = (l == 0) ? 0ull : (~0ull >> (64 - l));
       if (isStart) { const uint32_t k = R + (uint32_t)__popcll(ms & below); if (k < regCap) regS[k] = i; }
@@ -317,14 +390,23 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   __shared__ uint8_t s_degS[STRUCT_DEG_CAP], s_degE[STRUCT_DEG_CAP];
   unsigned long long m = 0;
   uint32_t vmax = 0;
-  for (uint32_t i = l; i < n; i += 64) { const uint32_t x = cov[i].x; if (x >= MINC) { m += 1; vmax = max(vmax, x); } }
-  m = wave_sum_u64(m);
+  // one pass over the hits: their number, their largest count and — optimistically — the histogram of the counts below
+  // STRUCT_HBINS (used when vmax turns out to be below it, which it nearly always is)
+  for (int b = l; b < STRUCT_HBINS; b += 64) s_hist[b] = 0;
+  WSYNC();
 #ifdef TALC_PROF
   unsigned long long nFork = 0;   // solid k-mers with more than one successor or predecessor in the graph (per-read rows)
-  for (uint32_t i = l; i < n; i += 64) {
-    const uint2 c = cov[i];
-    nFork += ((c.x >= MINC) && (c.y & kCovDegKnown) && ((((c.y >> kCovDegRShift) & 7u) > 1u) || (((c.y >> kCovDegLShift) & 7u) > 1u))) ? 1u : 0u;
-  }
+#endif
+  cov_for_hits(cov, n, [&](uint32_t x, uint32_t y) {
+    if (x >= MINC) { m += 1; vmax = max(vmax, x); if (x < (uint32_t)STRUCT_HBINS) atomicAdd(&s_hist[x], 1u); }
+#ifdef TALC_PROF
+    nFork += ((x >= MINC) && (y & kCovDegKnown) && ((((y >> kCovDegRShift) & 7u) > 1u) || (((y >> kCovDegLShift) & 7u) > 1u))) ? 1u : 0u;
+#else
+    (void)y;
+#endif
+  });
+  m = wave_sum_u64(m);
+#ifdef TALC_PROF
   nFork = wave_sum_u64(nFork);
 #endif
   vmax = wave_max_u32(vmax);
@@ -332,9 +414,6 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   if (m > 10) { first = (uint32_t)(0.15 * (double)m); last = (uint32_t)(0.90 * (double)m); }
   unsigned long long sum;
   if (vmax < (uint32_t)STRUCT_HBINS) {
-    for (int b = l; b < STRUCT_HBINS; b += 64) s_hist[b] = 0;
-    WSYNC();
-    for (uint32_t i = l; i < n; i += 64) { const uint32_t x = cov[i].x; if (x >= MINC) atomicAdd(&s_hist[x], 1u); }
     WSYNC();
     unsigned long long cMine = 0, sMine = 0;
     for (int b = 0; b < STRUCT_HBINS / 64; ++b) { const uint32_t v = (uint32_t)(l * (STRUCT_HBINS / 64) + b), h = s_hist[v]; cMine += h; sMine += (unsigned long long)h * v; }
@@ -359,7 +438,7 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   for (uint32_t base = 0; base < Rdeg; base += 64) {
     const uint32_t reg = base + l;
     if (reg < Rdeg) {   // region ends are IN k-mers, i.e. k-mers of the table: k_coverage left their degrees in cov[].y
-      const uint32_t ys = cov[regS[reg]].y, ye = cov[regE[reg]].y;
+      const uint32_t ys = cov_at(cov, regS[reg]).y, ye = cov_at(cov, regE[reg]).y;
       uint64_t km, nm;
       if (ys & kCovDegKnown) s_degS[reg] = (uint8_t)((ys >> kCovDegLShift) & 7u);
       else { lane_kmer_at(read + regS[reg], (int)K, km, nm); s_degS[reg] = (uint8_t)dev_out_degree(T, MINC, km, nm, 0); }
@@ -371,7 +450,7 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
 
   // out-degree of the k-mer at a wave-uniform position: from the coverage word when k_coverage knew the k-mer
   auto degree_of = [&](uint32_t pos, int dirRight) -> int {
-    const uint32_t y = (uint32_t)uni((int)cov[pos].y);
+    const uint32_t y = (uint32_t)uni((int)cov_at(cov, pos).y);
     if (y & kCovDegKnown) return (int)((y >> (dirRight ? kCovDegRShift : kCovDegLShift)) & 7u);
     uint64_t km, nm;
     wave_kmer_at(read + pos, (int)K, km, nm);
@@ -424,7 +503,7 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
         }
         if (OK) {
           uint32_t c = 0;
-          for (uint32_t i = new_start_pos + l; i <= new_end_pos; i += 64) c = max(c, cov[i].x);
+          for (uint32_t i = new_start_pos + l; i <= new_end_pos; i += 64) c = max(c, cov_at(cov, i).x);
           c = wave_max_u32(c);
           const bool expected = !is_expected_by_model(P.ALPHA, c, solidThr, true);
           if (expected) {
@@ -460,6 +539,23 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     checok &= (len == (unsigned long long)L);
   }
   st.nRegions = Rfinal;
+  // the counts of the read's first kHeadCov positions, dense (one 64-byte line per read): the count the reference records
+  // with anchor number a of a region is m_coverage[a] — a position of the READ (Explorer.cpp:454,520) — and every anchor
+  // list of the read asks for it
+  if (l < kHeadCov) headCov[(uint64_t)r * kHeadCov + (uint32_t)l] = ((uint32_t)l < n) ? cov_at(cov, (uint32_t)l).x : 0u;
+  {   // where each region's pairs start in the read's hit array, for the anchor search (k_search): the index of the
+      // region's first pair, and kRegClean when every position of the region is a hit of one tile, i.e. when the pair of
+      // position p is simply at index + (p - start) — nearly always; a region merged over a gap or one that crosses a tile
+      // is addressed position by position through the bitmap words
+    WSYNC();
+    uint32_t* regH = regS + 2 * regCap;
+    for (uint32_t i = l; i < Rfinal; i += 64) {
+      const uint32_t s0 = regS[i], e0 = regE[i];
+      const uint32_t hs = cov_hit_index(cov, s0);
+      const bool clean = ((s0 ^ e0) < (uint32_t)TALC_COV_TILE) && (e0 >= s0) && (cov_hit_index(cov, e0) - hs == e0 - s0);
+      regH[i] = (hs & ~kRegClean) | (clean ? kRegClean : 0u);
+    }
+  }
   {   // Read.cpp:423 on the regions as defineStructure2 leaves them (k_search redoes it for the reads it corrects)
     unsigned long long part = 0;
     for (uint32_t i = l; i < Rfinal; i += 64) part += (unsigned long long)regE[i] - regS[i] + 1;
@@ -598,6 +694,10 @@ struct Wv {
   uint32_t rowStride, rowAvail;    // the current search's records: ints per record, records (0: none)
   uint32_t wideMask;               // words - 1 of the current search's wide filter; 0: the LDS filter is in use
   uint32_t launchStamp;            // a number no other k_search launch of this process carries (stamps the kept rows)
+  const CovWord* covw;             // the current read's coverage words (cov: its hit pairs; talc_common.h)
+  uint32_t* regH;                  // hit index of every region's start | kRegClean (k_structure), kept in step with regS
+  uint32_t LH, RH;                 // ... of the current LEFT / RIGHT region
+  const uint32_t* headCov;         // the current read's kHeadCov dense counts
 };
 
 enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
@@ -629,8 +729,13 @@ __shared__ uint32_t g_prof[PF_N];   // per wave, in cycles: 2^32 cycles = 1.9 s 
 #define PROF_END2(cat) ((void)0)
 #endif
 
-#define COVX(i) (((const uint2 TALC_AS1*)X.cov)[(i)].x)
-#define COVY(i) (((const uint2 TALC_AS1*)X.cov)[(i)].y)
+// count / colour word of the k-mer at position i of the current read (0 when it is not in the table)
+TALC_D CovRead cur_cov() { CovRead c; c.hits = (const uint2 TALC_AS1*)X.cov; c.words = (const CovWord TALC_AS1*)X.covw; return c; }
+// (a real, cold call: the anchor search reads nearly everything through a region's hit index, and this body at every
+//  fallback site was several hundred instructions of the search's code)
+TALC_DNC unsigned long long cov_lookup(uint32_t i) { const uint2 v = cov_at(cur_cov(), i); return ((unsigned long long)v.y << 32) | v.x; }
+#define COVX(i) ((uint32_t)cov_lookup(i))
+#define COVY(i) ((uint32_t)(cov_lookup(i) >> 32))
 
 // DP arrays of the slow paths (sequences longer than the register-resident routines handle):
 // always the per-wave HBM arrays, so no pointer ever mixes LDS and HBM provenance.
@@ -936,7 +1041,34 @@ TALC_DN void build_anchors(int side) {
   // still IN, starts a new level and is recorded (Explorer.cpp:427-447 / 493-513).  64 positions per pass: every lane
   // tests its position against the current level; the first lane that stops either becomes the new level (the lanes
   // behind it are tested again) or ends the walk.
-  uint32_t current_count = COVX(pivot);
+  // The coverage the walks below look at, fetched ONCE, one position per lane: the region's pairs when it has at most 64
+  // k-mers (nearly always), and the counts of the read's first kHeadCov positions (the count the reference records for
+  // anchor number a is m_coverage[a], Explorer.cpp:454,520: a position of the read, not of the region; k_structure left
+  // them in one line per read).  Everything after this is lane traffic; a longer region (or a later anchor number)
+  // reads memory position by position.
+  const CovRead cr = cur_cov();
+  const bool inRegs = nbKmers <= 64u;
+  uint2 regv = make_uint2(0u, 0u), headv = make_uint2(0u, 0u);
+  // (a clean region — k_structure — holds the pair of position p at its start's index + (p - start): one load, no word)
+  const uint32_t regHidx = (uint32_t)uni((int)(side == 0 ? X.LH : X.RH));
+  const bool clean = (regHidx & kRegClean) != 0u;
+  const uint32_t hbase = regHidx & ~kRegClean;
+  if (inRegs && (uint32_t)l < nbKmers) {
+    if (clean) { const v2u32 e = *(const v2u32 TALC_AS1*)(cr.hits + hbase + (uint32_t)l); regv = make_uint2(e.x, e.y); }
+    else regv = cov_at(cr, rs + (uint32_t)l);
+  }
+  if (l < kHeadCov) headv.x = ((const uint32_t TALC_AS1*)X.headCov)[l];
+  // ... parked in the wave's DP stage (LDS; no alignment routine runs inside this function): values that lived in vector
+  // registers over this function's calls would each cost a stack save and a restore per call of it
+  uint32_t TALC_AS3* const park = (uint32_t TALC_AS3*)g_dp;
+  park[l] = regv.x; park[64 + l] = regv.y; park[128 + l] = headv.x;
+  LSYNC();
+  auto run_x = [&](uint32_t pos) -> uint32_t { return park[(pos - rs) & 63u]; };
+  auto run_y = [&](uint32_t pos) -> uint32_t { return park[64u + ((pos - rs) & 63u)]; };
+#define RUNX(pos) (inRegs ? run_x(pos) : (clean ? (*(const v2u32 TALC_AS1*)(cr.hits + hbase + ((pos) - rs))).x : COVX(pos)))
+#define RUNY(pos) (inRegs ? run_y(pos) : (clean ? (*(const v2u32 TALC_AS1*)(cr.hits + hbase + ((pos) - rs))).y : COVY(pos)))
+#define HEADX(a) (((a) < (uint32_t)kHeadCov) ? (uint32_t)uni((int)park[128u + (a)]) : COVX(a))
+  uint32_t current_count = (uint32_t)uni((int)RUNX(pivot));
   uint32_t nPos = 0;
   if (l == 0) anchorPos[0] = pivot;
   nPos = 1;
@@ -947,7 +1079,8 @@ TALC_DN void build_anchors(int side) {
       const uint32_t idx = visited + (uint32_t)l;
       const bool valid = idx < remaining;
       const uint32_t pos = (side == 0) ? (pivot - 1 - idx) : (pivot + 1 + idx);
-      const uint32_t nc = valid ? COVX(pos) : 0u;
+      const uint32_t ncAll = RUNX(valid ? pos : pivot);
+      const uint32_t nc = valid ? ncAll : 0u;
       const bool inRange = valid & (nc >= MINC) & ((double)nc < P.MAX_IN_COUNT);
       int from = 0;
       while (from < 64) {
@@ -973,7 +1106,8 @@ TALC_DN void build_anchors(int side) {
   const int degDir = (side == 0) ? 1 : 0;
   const int degShift = (side == 0) ? kCovDegRShift : kCovDegLShift;
   auto degree_at = [&](bool want, uint32_t pos) -> int {
-    const uint32_t cy = want ? COVY(pos) : kCovDegKnown;
+    const uint32_t cyAll = RUNY(want ? pos : pivot);
+    const uint32_t cy = want ? cyAll : kCovDegKnown;
     int degree = (int)((cy >> degShift) & 7u);
     const bool unknown = want && !(cy & kCovDegKnown);
     if (ballot64(unknown) != 0ull) {
@@ -995,7 +1129,8 @@ TALC_DN void build_anchors(int side) {
         const uint32_t pf = (uint32_t)lane_get((int)pos, f);
         uint64_t km, nm;
         wave_kmer_at(X.read + pf, (int)K, km, nm);
-        if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, COVX(base + (uint32_t)f)};
+        const uint32_t recorded = HEADX(base + (uint32_t)f);
+        if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, recorded};
         if (nAnc == 0) firstAnchorPos = pf;
         ++nAnc;
       } else X.overflow |= OVF_ANCHORS;
@@ -1026,7 +1161,8 @@ TALC_DN void build_anchors(int side) {
             const uint32_t pf = (uint32_t)lane_get((int)pos, f);
             uint64_t km, nm;
             wave_kmer_at(X.read + pf, (int)K, km, nm);
-            if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, COVX(pf)};
+            const uint32_t cpf = (uint32_t)uni((int)RUNX(pf));
+            if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, cpf};
             ++nAnc;
           } else { X.overflow |= OVF_ANCHORS; full = true; break; }
         }
@@ -1041,7 +1177,8 @@ TALC_DN void build_anchors(int side) {
           wave_kmer_at(X.read + (j + 1), (int)K, km, nm);
           const int degree = dev_out_degree(X.T, MINC, km, nm, 0);
           if (degree > 1) {
-            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j + 1, COVX(j + 1)}; ++nAnc; }
+            const uint32_t cj1 = (uint32_t)uni((int)RUNX(j + 1));
+            if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j + 1, cj1}; ++nAnc; }
             else X.overflow |= OVF_ANCHORS;
           }
         }
@@ -1058,6 +1195,9 @@ TALC_DN void build_anchors(int side) {
   }
   WSYNC();
   if (side == 0) X.nAncL = (int)nAnc; else X.nAncR = (int)nAnc;
+#undef RUNX
+#undef RUNY
+#undef HEADX
   PROF_END(PF_ANCHORS);
 }
 
@@ -2184,8 +2324,17 @@ TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
 // A bridge's search also enters its aims (the target anchors, Explorer.cpp:920) in the search's filter: the
 // fast-forward loop then needs no aim comparison of its own (a step onto an aim is a filter hit).
-TALC_D void init_first_trail(const AnchorRec& a, bool withAims, uint32_t pathMax) {
+TALC_D void init_first_trail(const AnchorRec& a, const AnchorRec* inList, bool withAims, uint32_t pathMax) {
   const int K = (int)X.P.K;
+  // the first Trail's count (Trail.cpp:57-65: the coverage at the anchor): two dependent loads, word then pair, requested
+  // here and consumed at the end, behind everything else this function does
+  uint32_t firstCount;
+  {
+    const uint32_t h = (uint32_t)uni((int)(X.dirRight ? X.LH : X.RH)), rs0 = (uint32_t)uni((int)(X.dirRight ? X.Ls : X.Rs));
+    if ((h & kRegClean) != 0u && a.pos >= rs0) firstCount = (*(const v2u32 TALC_AS1*)((const uint2 TALC_AS1*)X.cov + (h & ~kRegClean) + (a.pos - rs0))).x;
+    else firstCount = COVX(a.pos);
+  }
+  (void)inList;
   pool_reset();
   const uint32_t b0 = (uint32_t)pool_alloc();
   wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
@@ -2222,7 +2371,7 @@ TALC_D void init_first_trail(const AnchorRec& a, bool withAims, uint32_t pathMax
   bloom_query_insert(a.kmer, a.nmask);
   if (lane_id() == 0) {
     TrailRec r;
-    r.kmer = a.kmer; r.nmask = a.nmask; r.cnt = COVX(a.pos); r.score = 0; r.fail = 0; r.dist = 0.0;
+    r.kmer = a.kmer; r.nmask = a.nmask; r.cnt = firstCount; r.score = 0; r.fail = 0; r.dist = 0.0;
     r.lanc = X.dirRight ? (int)a.pos : -1;
     r.ranc = X.dirRight ? -1 : (int)a.pos;
     r.buf = b0;
@@ -2290,7 +2439,7 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
     if (!pool_shape(PATH_MAXLENGTH)) return false;
     rows_shape();
-    PROF_BEGIN2(); init_first_trail(a, true, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
+    PROF_BEGIN2(); init_first_trail(a, anchors + s, true, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
     const uint32_t maxInner = (uint32_t)uni((int)P.MAX_INNER_PATHS);
@@ -2420,7 +2569,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     WSYNC();
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
     if (!pool_shape(PATH_MAXLENGTH)) return false;
-    PROF_BEGIN2(); init_first_trail(a, false, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
+    PROF_BEGIN2(); init_first_trail(a, anchors + s, false, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
     int nCur = 1;
     int len = (int)K;
     while ((int)(nCur > 0) & (int)((uint32_t)nCur <= maxInner) & (int)((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH) & (int)(uni((int)X.overflow) == 0)) {
@@ -2486,8 +2635,10 @@ TALC_D void trace_search() {
 #endif
 __global__ void __launch_bounds__(64, TALC_SEARCH_WAVES_PER_SIMD)
 k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
-         const uint64_t* __restrict__ koff, const uint2* __restrict__ covAll, ReadState* __restrict__ state,
-         const uint32_t* __restrict__ regions, const uint64_t* __restrict__ regoff, uint8_t* __restrict__ outAll,
+         const uint64_t* __restrict__ koff, const uint2* __restrict__ covAll, const CovWord* __restrict__ covWords,
+         ReadState* __restrict__ state,
+         const uint32_t* __restrict__ regions, const uint64_t* __restrict__ regoff, const uint32_t* __restrict__ headCovAll,
+         uint8_t* __restrict__ outAll,
          const uint64_t* __restrict__ outoff, const uint32_t* __restrict__ order, uint32_t n_work,
          uint32_t* __restrict__ queue, uint8_t* __restrict__ scratchAll, uint64_t* __restrict__ counters, TraceBuf trace,
          uint32_t traceRead, uint32_t launchStamp, uint32_t flags) {
@@ -2516,7 +2667,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     X.gRank = (Rank4*)g; g += 32ull * (TCAP + 64);
     X.gKept = (uint32_t*)g;
   }
-  X.regS = (uint32_t*)(slot + C.o_regS); X.regE = (uint32_t*)(slot + C.o_regE);
+  X.regS = (uint32_t*)(slot + C.o_regS); X.regE = (uint32_t*)(slot + C.o_regE); X.regH = (uint32_t*)(slot + C.o_regH);
   X.wOff = (uint32_t*)(slot + C.o_wOff); X.wLen = (uint32_t*)(slot + C.o_wLen);
   X.weak = slot + C.o_weak;
   X.trace = trace;
@@ -2556,7 +2707,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     uint8_t* out = outAll + outoff[r];
     const uint32_t outCap = (uint32_t)(outoff[r + 1] - outoff[r]);
     ReadState st = state[r];
-    X.read = codes + rb; X.L = L; X.n = L >= P.K ? L - P.K + 1 : 0; X.cov = covAll + koff[r]; X.lambda = st.lambda;
+    X.read = codes + rb; X.L = L; X.n = L >= P.K ? L - P.K + 1 : 0; X.cov = covAll + koff[r]; X.covw = covWords + cov_word_base(koff[r], r); X.headCov = headCovAll + (uint64_t)r * kHeadCov; X.lambda = st.lambda;
     X.cells = 0; X.steps = 0; X.overflow = 0; X.complexRegion = false; X.ffPopped = false;
     X.tracing = (trace.recs != nullptr) && (r == traceRead);
 
@@ -2570,9 +2721,11 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     const uint32_t R = st.nRegions;
     if (R > C.regCap) { X.overflow |= OVF_REGIONS; }
     else {
-      const uint32_t* gS = regions + 2 * regoff[r];
-      const uint32_t* gE = gS + (uint32_t)(regoff[r + 1] - regoff[r]);
-      for (uint32_t i = l; i < R; i += 64) { X.regS[i] = gS[i]; X.regE[i] = gE[i]; X.wLen[i] = 0xFFFFFFFFu; X.wOff[i] = 0; }
+      const uint32_t* gS = regions + 3 * regoff[r];
+      const uint32_t gCap = (uint32_t)(regoff[r + 1] - regoff[r]);
+      const uint32_t* gE = gS + gCap;
+      const uint32_t* gH = gE + gCap;
+      for (uint32_t i = l; i < R; i += 64) { X.regS[i] = gS[i]; X.regE[i] = gE[i]; X.regH[i] = gH[i]; X.wLen[i] = 0xFFFFFFFFu; X.wOff[i] = 0; }
     }
     WSYNC();
     uint32_t weakUsed = 0;
@@ -2594,6 +2747,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
           // initializeINNER (Explorer.cpp:228-243)
           X.location = LOC_INNER; X.dirRight = (attempt == 0) ? 1 : 0;
           X.Ls = X.regS[reg]; X.Le = X.regE[reg]; X.Rs = X.regS[reg + 1]; X.Re = X.regE[reg + 1];
+          X.LH = X.regH[reg]; X.RH = X.regH[reg + 1];
           X.weakLen = (X.Rs > X.Le + K) ? (X.Rs - (X.Le + K)) : 0;
           // (the LEFT attempt after a failed RIGHT one starts from the same two regions — a failed search changes
           //  neither — so anchorLEFTHandSide / anchorRIGHTHandSide, Explorer.cpp:239-240, would return the lists again)
@@ -2607,13 +2761,14 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         }
         // updateINNER (Read.cpp:294-303)
         WSYNC();
-        if (success && l == 0) { X.regE[reg] = X.Le; X.regS[reg + 1] = X.Rs; X.wOff[reg] = wo; X.wLen[reg] = wl; }
+        // (a region's start only ever moves inward: its hit index moves with it)
+        if (success && l == 0) { X.regE[reg] = X.Le; X.regH[reg + 1] += X.Rs - X.regS[reg + 1]; X.regS[reg + 1] = X.Rs; X.wOff[reg] = wo; X.wLen[reg] = wl; }
         WSYNC();
       }
       // ---- head (Read.cpp:361-367)
       if (!X.overflow && headPresent && headLen <= P.MAX_BORDER_LEN) {
         X.location = LOC_HEAD; X.dirRight = 0;
-        X.Rs = X.regS[0]; X.Re = X.regE[0]; X.Ls = 0; X.Le = 0;
+        X.Rs = X.regS[0]; X.Re = X.regE[0]; X.Ls = 0; X.Le = 0; X.RH = X.regH[0]; X.LH = 0;
         X.weakLen = X.Rs;
         X.nAncL = 0;
         build_anchors(1);
@@ -2624,13 +2779,13 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
           else trace_rec(TR_RESULT, 0, 0, 0, (int)X.regS[0], 0.0, X.read, X.weakLen, false);
         }
         WSYNC();
-        if (headCorr && l == 0) X.regS[0] = X.Rs;   // updateHEAD (Read.cpp:305-311)
+        if (headCorr && l == 0) { X.regH[0] += X.Rs - X.regS[0]; X.regS[0] = X.Rs; }   // updateHEAD (Read.cpp:305-311)
         WSYNC();
       }
       // ---- tail (Read.cpp:368-374)
       if (!X.overflow && tailPresent && tailLen <= P.MAX_BORDER_LEN) {
         X.location = LOC_TAIL; X.dirRight = 1;
-        X.Ls = X.regS[R - 1]; X.Le = X.regE[R - 1]; X.Rs = 0; X.Re = 0;
+        X.Ls = X.regS[R - 1]; X.Le = X.regE[R - 1]; X.Rs = 0; X.Re = 0; X.LH = X.regH[R - 1]; X.RH = 0;
         X.weakLen = L - (X.Le + K);
         X.nAncR = 0;
         build_anchors(0);

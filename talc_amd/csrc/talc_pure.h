@@ -14,6 +14,7 @@
 // Floating point: IEEE double, no contraction (-ffp-contract=off), sqrt and division correctly
 // rounded on both sides; std::pow(x,2) of the reference is x*x (g++ folds it).
 #pragma once
+#include <cstddef>
 #include <math.h>
 
 #include "talc_common.h"
@@ -291,8 +292,10 @@ struct AnchorRec {
   uint64_t kmer;    // packed natural orientation; bases under an N are 0
   uint64_t nmask;   // bit i set <=> base i (0 = first) is N
   uint32_t pos;
-  uint32_t count;
+  uint32_t count;   // the count the reference records with the anchor (m_coverage[anchor number], Explorer.cpp:454,520)
 };
+// (24 bytes on purpose: a 32-byte record with the anchor's own coverage count in it made k_search 2 ms slower on config 2
+//  — same-box A/B, whatever the stride of the waves' scratch slots — while saving one load per search)
 struct LessAnchor {
   double cc;
   TALC_HD bool operator()(const AnchorRec& l, const AnchorRec& r) const {
