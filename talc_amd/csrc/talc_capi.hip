@@ -485,7 +485,7 @@ int talc_table_upload(talc_table* t, int device) {
       } else {
         const uint64_t nthr = 2 * t->h.capacity;
         hipLaunchKernelGGL(k_build_walk, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, 0, dc.right, dc.left, t->h.capacity,
-                           t->h.p.k, dc.walkRight, dc.walkLeft);
+                           t->h.p.k, (uint32_t)t->h.p.min_count, dc.walkRight, dc.walkLeft);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
       }

@@ -87,23 +87,27 @@ TALC_HD uint64_t cov_word_base(uint64_t koff, uint32_t read_index) { return (kof
 TALC_HD uint64_t cov_words_total(uint64_t n_kmers, uint32_t n_reads) { return (n_kmers >> 6) + n_reads + 1; }
 
 // Walk table (device only, derived from a finished Bucket table, same capacity and slot order): what a Trail that
-// keeps following its only solid successor will meet over the next WALK_LEVELS steps, in one 64-byte record, so
-// that the single-Trail fast-forward pays one dependent memory access per WALK_LEVELS steps instead of per step.
+// keeps following its only solid successor will meet over the next WALK_LEVELS steps, in one 32-byte record — the size
+// of a bucket, so the two walk tables cost as much device memory as the two bucket tables (64-byte records with 32-bit
+// levels, rounds 1-2, cost twice that: 141 GB behind 70 GB of buckets at 547 M k-mers) — so that the single-Trail
+// fast-forward pays one dependent memory access per WALK_LEVELS steps instead of per step.
 // Level 0 describes the bucket's own four counts, level j+1 the bucket reached from level j by appending level j's
-// largest-count base.  One 32-bit word per level: bits 0-15 top = the largest count (0xFFFF: does not fit, the walk
-// stops at this level), bits 16-29 next = the largest of the other three clamped to 2^14-1, bits 30-31 the base of
-// `top`.  "Exactly one successor with count >= MIN_COUNT" (the only kind of step the fast-forward takes) is
-// top >= MIN_COUNT > next, that successor is the stored base and its count is top — exact for any MIN_COUNT in
-// [1, 2^14); a level whose bucket does not exist is all zero (no step passes it).  Whatever a record cannot express
-// (a count beyond 16 bits, MIN_COUNT beyond 14) is left to the per-step form / the generic step: never wrong, only slower.
-#define TALC_WALK_LEVELS 14
-struct __attribute__((aligned(64))) WalkEntry {
+// largest-count base.  One 16-bit word per level: bits 0-12 top = the largest count (0x1FFF: does not fit, the walk
+// stops at this level), bit 13 single = "exactly one successor with count >= MIN_COUNT" (top >= MIN_COUNT > the largest
+// of the other three) for the MIN_COUNT the table was filtered with — the only one a context may run it with
+// (talc_ctx_create) —, bits 14-15 the base of `top`.  The only kind of step the fast-forward takes is a level with
+// `single` set: that successor is the stored base and its count is top; a level whose bucket does not exist is all
+// zero (no step passes it).  Whatever a record cannot express (a count beyond 13 bits) is left to the per-step form /
+// the generic step: never wrong, only slower.
+#define TALC_WALK_LEVELS 12
+struct __attribute__((aligned(32))) WalkEntry {
   uint64_t key;                      // the bucket's key (kEmptyKey if unused)
-  uint32_t lvl[TALC_WALK_LEVELS];    // top | next << 16 | base << 30 per level
+  uint16_t lvl[TALC_WALK_LEVELS];    // top | single << 13 | base << 14 per level
 };
-static_assert(sizeof(WalkEntry) == 64, "walk entry must be 64 bytes");
-static const uint32_t kWalkTopNone = 0xFFFFu;
-static const uint32_t kWalkNextMask = 0x3FFFu;
+static_assert(sizeof(WalkEntry) == 32, "walk entry must be 32 bytes");
+static const uint32_t kWalkTopNone = 0x1FFFu;
+static const uint32_t kWalkSingle = 1u << 13;
+static const int kWalkBaseShift = 14;
 
 struct TableView {
   const Bucket* right;   // device (or host) pointer

@@ -219,7 +219,7 @@ __global__ void k_build_indegree(Bucket* __restrict__ right, const Bucket* __res
 // ------------------------------------------------------------------ walk tables (WalkEntry, talc_common.h)
 // One thread per bucket of either table: level 0 from the bucket's own counts, then up to WALK_LEVELS-1 dependent
 // probes along the largest-count successor.  Runs once per upload.
-TALC_D uint32_t walk_level(const uint32_t c[4], uint32_t& top) {
+TALC_D uint32_t walk_level(const uint32_t c[4], uint32_t min_count, uint32_t& top) {
   uint32_t am = 0;
   top = c[0];
 #pragma unroll
@@ -227,11 +227,13 @@ TALC_D uint32_t walk_level(const uint32_t c[4], uint32_t& top) {
   uint32_t nx = 0;
 #pragma unroll
   for (uint32_t b = 0; b < 4; ++b) if (b != am && c[b] > nx) nx = c[b];
-  return (top < kWalkTopNone ? top : kWalkTopNone) | ((nx < kWalkNextMask ? nx : kWalkNextMask) << 16) | (am << 30);
+  const bool fits = top < kWalkTopNone;
+  const bool single = fits && top >= min_count && nx < min_count;
+  return (fits ? top : kWalkTopNone) | (single ? kWalkSingle : 0u) | (am << kWalkBaseShift);
 }
 
 __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __restrict__ left, uint64_t cap, uint32_t K,
-                             WalkEntry* __restrict__ walkRight, WalkEntry* __restrict__ walkLeft) {
+                             uint32_t min_count, WalkEntry* __restrict__ walkRight, WalkEntry* __restrict__ walkLeft) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 2 * cap) return;
   const bool dirRight = j < cap;
@@ -248,20 +250,19 @@ __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __r
 #pragma unroll
     for (int lev = 0; lev < TALC_WALK_LEVELS; ++lev) {
       uint32_t top;
-      const uint32_t w = walk_level(r.cnt, top);
+      const uint32_t w = walk_level(r.cnt, min_count, top);
       lv[lev] = w;
       if (top == 0 || top >= kWalkTopNone || lev == TALC_WALK_LEVELS - 1) break;   // nothing usable beyond this level
-      const uint64_t am = w >> 30;
+      const uint64_t am = w >> kWalkBaseShift;
       // successor key: RIGHT appends the base to the (K-1)-mer and drops its first base, LEFT prepends and drops the last
       key = dirRight ? (((key << 2) | am) & m1) : ((am << (2 * (K - 2))) | (key >> 2));
       if (!probe_bucket(tab, cap, key, r)) break;   // no such bucket: the remaining levels stay zero
     }
   }
+  static_assert(TALC_WALK_LEVELS == 12, "two 16-byte stores: the key and twelve 16-bit levels");
   v4u32 TALC_AS1* out = (v4u32 TALC_AS1*)((dirRight ? walkRight : walkLeft) + s);
-  out[0] = v4u32{(uint32_t)key0, (uint32_t)(key0 >> 32), lv[0], lv[1]};
-  out[1] = v4u32{lv[2], lv[3], lv[4], lv[5]};
-  out[2] = v4u32{lv[6], lv[7], lv[8], lv[9]};
-  out[3] = v4u32{lv[10], lv[11], lv[12], lv[13]};
+  out[0] = v4u32{(uint32_t)key0, (uint32_t)(key0 >> 32), lv[0] | (lv[1] << 16), lv[2] | (lv[3] << 16)};
+  out[1] = v4u32{lv[4] | (lv[5] << 16), lv[6] | (lv[7] << 16), lv[8] | (lv[9] << 16), lv[10] | (lv[11] << 16)};
 }
 
 }  // namespace talc

@@ -152,7 +152,10 @@ TALC_D uint32_t cov_right_degree(const TableView& T, uint64_t kmer, uint32_t min
   BucketRegs br;
   return probe_bucket(T.right, T.capacity, kmer & m1, br) ? bucket_degree(br, min_count) : 0u;
 }
-__global__ void __launch_bounds__(COV_THREADS)
+#ifndef COV_WAVES_PER_SIMD
+#define COV_WAVES_PER_SIMD 8
+#endif
+__global__ void __launch_bounds__(COV_THREADS, COV_WAVES_PER_SIMD * 64 / COV_THREADS > 0 ? COV_WAVES_PER_SIMD * 64 / COV_THREADS : 1)
 k_coverage(TableView T, const uint8_t* __restrict__ codes, const uint64_t* __restrict__ offsets,
            const uint64_t* __restrict__ koff, const uint32_t* __restrict__ tile_read,
            const uint32_t* __restrict__ tile_start, uint2* __restrict__ cov, CovWord* __restrict__ covWords,

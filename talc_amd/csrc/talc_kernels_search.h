@@ -2088,13 +2088,13 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
   return done;
 }
 
-// ---- walk-table form of the fast-forward: one 64-byte record (WalkEntry, talc_common.h) describes the next
+// ---- walk-table form of the fast-forward: one 32-byte record (WalkEntry, talc_common.h) describes the next
 // TALC_WALK_LEVELS steps of a Trail that keeps following its only solid successor, so a record's steps are taken
-// together, one level per lane: lane j < 14 loads level j (lanes 14, 15 the key), the lanes test "exactly one successor"
+// together, one level per lane: lane j < 12 loads level j (lanes 12, 13 the key), the lanes test "exactly one successor"
 // and build their k-mers from the prefix of the levels' bases, hash them, query the search's filter (LDS) — a
 // ballot gives the number of steps that can be committed, and those lanes insert their k-mers, store their bases
 // and record their counts.  One dependent memory access and ~130 instructions per record instead of per step.
-// A k-mer that repeats WITHIN a record (a cycle of period <= 13) would not be seen by a query that precedes the
+// A k-mer that repeats WITHIN a record (a cycle of period <= 11) would not be seen by a query that precedes the
 // record's inserts: lanes compare their hashes with the lower lanes' (equal hash = possible cycle = stop there).
 template <int P>
 TALC_D uint32_t dpp_row_shr(uint32_t v, uint32_t old) {
@@ -2112,7 +2112,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   if (uni((int)(X.tracing && X.trace.steps)) != 0) return 0;
   const TrailRec r0 = tr_get(X.ia, 0);
   if (uni64(r0.nmask) != 0ull) return 0;
-  const uint32_t K = (uint32_t)uni((int)P.K), MINC = (uint32_t)uni((int)P.MIN_COUNT), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
+  const uint32_t K = (uint32_t)uni((int)P.K), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
   const uint32_t seqCap = (uint32_t)uni((int)X.C.seqCap), PMAX = (uint32_t)uni((int)PATH_MAXLENGTH_);
   const uint64_t cap = uni64(X.T.capacity);
   const uint32_t TALC_AS1* wtab = (const uint32_t TALC_AS1*)uni_ptr(dirRight ? X.T.walkRight : X.T.walkLeft);
@@ -2158,8 +2158,10 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     PROF_END(PF_FFFLUSH);
   };
 
-  // lane j < 14 reads level j, lanes 14 / 15 the two halves of the key (the lanes above them repeat lane 14)
-  const uint32_t laneOff = (l < TALC_WALK_LEVELS) ? (uint32_t)(2 + l) : (l == TALC_WALK_LEVELS + 1 ? 1u : 0u);
+  // lane j < 12 reads the dword that holds level j (two 16-bit levels per dword), lanes 12 / 13 the two halves of the
+  // key (the lanes above them repeat lane 12)
+  const uint32_t laneOff = (l < TALC_WALK_LEVELS) ? (uint32_t)(2 + (l >> 1)) : (l == TALC_WALK_LEVELS + 1 ? 1u : 0u);
+  const uint32_t laneShift = (l < TALC_WALK_LEVELS && (l & 1)) ? 16u : 0u;
   const int lj = min(l, TALC_WALK_LEVELS - 1);                // shift amounts stay in range on the idle lanes
   uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
   uint32_t hh = (uint32_t)(table_hash(key) >> 32);
@@ -2172,7 +2174,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     if (done - flushed > 64 - TALC_WALK_LEVELS) flush();
     PROF_BEGIN();
     uint64_t slot = ((uint64_t)hh * (uint64_t)(uint32_t)cap) >> 32;
-    uint32_t e = havePre ? ePre : wtab[slot * 16 + laneOff];
+    uint32_t e = havePre ? ePre : wtab[slot * 8 + laneOff];
     havePre = false;
     bool found = true;
     while (true) {   // linear probing, as in the bucket table (same slots)
@@ -2180,7 +2182,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
       if (bk == key) break;
       if (bk == kEmptyKey) { found = false; break; }
       if (++slot == cap) slot = 0;
-      e = wtab[slot * 16 + laneOff];
+      e = wtab[slot * 8 + laneOff];
     }
     PROF_END(PF_FFLOAD);
 #ifdef TALC_PROF
@@ -2188,13 +2190,14 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
 #endif
     if (!found) break;
     PROF_BEGIN();
-    const uint32_t top = e & 0xFFFFu, next = (e >> 16) & kWalkNextMask;
-    // levels that are "exactly one successor with count >= MIN_COUNT", from level 0 up to the first that is not
-    const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && top != kWalkTopNone && top >= MINC && next < MINC);
+    const uint32_t lev = (e >> laneShift) & 0xFFFFu, top = lev & kWalkTopNone;
+    // levels that are "exactly one successor with count >= MIN_COUNT" (decided at upload for the table's MIN_COUNT, which
+    // is this context's), from level 0 up to the first that is not
+    const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && (lev & kWalkSingle) != 0u);
     int nOK = min(__builtin_ctzll(~passMask), maxSteps - done);
     if (nOK == 0) break;
     // lane j's tip after its step: the current tip shifted by j+1 bases, with the bases of levels 0..j
-    const uint32_t which = (l < TALC_WALK_LEVELS) ? (e >> 30) : 0u;
+    const uint32_t which = (l < TALC_WALK_LEVELS) ? (lev >> kWalkBaseShift) : 0u;
     uint32_t pre = which << (dirRight ? 2 * (TALC_WALK_LEVELS - 1 - lj) : 2 * lj);
     pre |= dpp_row_shr<1>(pre, 0u);
     pre |= dpp_row_shr<2>(pre, 0u);
@@ -2207,7 +2210,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     const uint32_t hv = (uint32_t)(table_hash(key2) >> 32);   // the filter hash of the new tip = the hash of its probe
     {
       const uint64_t slotN = ((uint64_t)(uint32_t)lane_get((int)hv, TALC_WALK_LEVELS - 1) * (uint64_t)(uint32_t)cap) >> 32;
-      ePre = wtab[slotN * 16 + laneOff];
+      ePre = wtab[slotN * 8 + laneOff];
     }
     // possible cycle inside the record: the same hash on a lower lane
     bool dup = dpp_row_shr<1>(hv, ~hv) == hv;
@@ -2221,9 +2224,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     dup |= dpp_row_shr<9>(hv, ~hv) == hv;
     dup |= dpp_row_shr<10>(hv, ~hv) == hv;
     dup |= dpp_row_shr<11>(hv, ~hv) == hv;
-    dup |= dpp_row_shr<12>(hv, ~hv) == hv;
-    dup |= dpp_row_shr<13>(hv, ~hv) == hv;
-    static_assert(TALC_WALK_LEVELS == 14, "the lane roles above are written for 14 levels in a 16-lane row");
+    static_assert(TALC_WALK_LEVELS == 12, "the lane roles above are written for 12 levels (+ 2 key lanes) in a 16-lane row");
     // aim / cycle query against the search's filter (init_first_trail entered the aims)
     const int bwi = (int)(hv >> 25);     // bloom_word / bloom_mask on the upper half of the hash
     unsigned long long bm = (1ull << ((hv >> 19) & 63u)) | (1ull << ((hv >> 13) & 63u));
@@ -2312,7 +2313,7 @@ TALC_DNC int fast_forward_wide(int len, uint32_t& stepCounter, uint32_t PATH_MAX
 }
 TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
   // the walk tables encode "count >= MIN_COUNT" for MIN_COUNT below 2^14 only (talc_common.h)
-  if (uni((int)(X.T.walkRight != nullptr && X.P.MIN_COUNT <= kWalkNextMask)) != 0)
+  if (uni((int)(X.T.walkRight != nullptr && X.P.MIN_COUNT < kWalkTopNone)) != 0)
   {
     if (uni((int)X.wideMask) != 0) [[clang::musttail]] return fast_forward_wide(len, stepCounter, PATH_MAXLENGTH, edge);
     return uni((int)X.dirRight) ? fast_forward_walk<true, false>(len, stepCounter, PATH_MAXLENGTH, edge)
@@ -2345,7 +2346,7 @@ TALC_D void init_first_trail(const AnchorRec& a, const AnchorRec* inList, bool w
   // the search's cycle filter: the wave's 8192 bits of LDS, or — for a Trail that may grow to thousands of k-mers, and
   // when the walk-table form of the fast-forward (the one that can read it) is in use — the wide one in HBM
   uint32_t wm = 0;
-  if (pathMax > (uint32_t)WIDE_BLOOM_MIN_PATH && X.wideBloom != nullptr && X.T.walkRight != nullptr && X.P.MIN_COUNT <= kWalkNextMask) {
+  if (pathMax > (uint32_t)WIDE_BLOOM_MIN_PATH && X.wideBloom != nullptr && X.T.walkRight != nullptr && X.P.MIN_COUNT < kWalkTopNone) {
     uint32_t words = 1024;
     while (words < (uint32_t)WIDE_BLOOM_WORDS && words < pathMax / 2) words <<= 1;
     wm = words - 1;

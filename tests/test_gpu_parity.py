@@ -593,20 +593,20 @@ def test_walk_tables_do_not_change_results(gpu_pair, monkeypatch):
 
 @pytest.mark.parametrize("form", ["walk-clamped", "per-step"])
 def test_walk_tables_with_counts_beyond_their_fields(form):
-    """A walk level holds the largest count in 16 bits (larger: the walk stops there and the generic step takes over)
-    and the runner-up clamped to 14 bits, which is exact for MIN_COUNT < 2^14; above that the fast-forward must not
-    use the walk tables at all."""
+    """A walk level holds the largest count in 13 bits (larger: the walk stops there and the generic step takes over)
+    and a flag "exactly one successor >= MIN_COUNT" for the table's MIN_COUNT; a MIN_COUNT that does not fit the
+    count field makes the fast-forward use the per-step form instead of the walk tables."""
     from talc_amd.synth import Synth
     S = Synth(target_kmers=200_000, k=21, seed=23)
     keys, counts = S.dump_arrays()
     if form == "walk-clamped":     # counts x 700: about a third of them above 16383, a few percent above 65535
         big = (counts.astype(np.uint64) * 700).astype(np.uint32)
         minc = 2 * 700
-        assert minc < (1 << 14) and int((big > 65535).sum()) > 100 and int((big > 16383).sum()) > 10000
+        assert minc < 0x1FFF and int((big > 65535).sum()) > 100 and int((big > 0x1FFF).sum()) > 10000
     else:                          # MIN_COUNT itself beyond 14 bits
         big = (counts.astype(np.uint64) * 9000).astype(np.uint32)
         minc = 2 * 9000
-        assert minc > (1 << 14)
+        assert minc > 0x1FFF
     p, q = PU.both_params(k=21, min_count=minc)
     otab = O.OracleTable(q, O.OracleTable.FLAT)
     otab.insert_packed(keys, big)
