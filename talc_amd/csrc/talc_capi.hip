@@ -708,7 +708,8 @@ int talc_batch_create(talc_ctx* c, const char* bases, const uint64_t* offsets, u
   hipStream_t s = c->stream;
   int rc;
   if ((rc = ctx_alloc(c, (void**)&b->d_raw, std::max<uint64_t>(b->n_bases, 1)))) return rc;
-  if ((rc = ctx_alloc(c, (void**)&b->d_codes, std::max<uint64_t>(b->n_bases, 1)))) return rc;
+  // (+ 64: a search may read a stretch of a read in place, and the wave routines fetch whole 8- and 16-byte words)
+  if ((rc = ctx_alloc(c, (void**)&b->d_codes, std::max<uint64_t>(b->n_bases, 1) + 64))) return rc;
   if (b->n_bases) HIPCHK(hipMemcpyAsync(b->d_raw, bases, b->n_bases, hipMemcpyHostToDevice, s));
   if ((rc = up(c, &b->d_offsets, b->h_offsets, s))) return rc;
   if ((rc = up(c, &b->d_koff, b->h_koff, s))) return rc;

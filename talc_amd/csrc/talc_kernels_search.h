@@ -649,11 +649,11 @@ struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online 
 enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
        PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
        PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX,
-       PF_XSTAGE, PF_XLEV, PF_XSEL, PF_N };
+       PF_XSTAGE, PF_XLEV, PF_XSEL, PF_REFB, PF_RESULT, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
                        "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
                        "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords", "#reads<0.25ms", "#reads<1ms", "#reads<4ms", \
-                       "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)", "x.stage", "x.levels", "x.select"}
+                       "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)", "x.stage", "x.levels", "x.select", "b.ref", "b.result"}
 
 struct Wv {
   // kernel constants
@@ -698,6 +698,7 @@ struct Wv {
   uint32_t* regH;                  // hit index of every region's start | kRegClean (k_structure), kept in step with regS
   uint32_t LH, RH;                 // ... of the current LEFT / RIGHT region
   const uint32_t* headCov;         // the current read's kHeadCov dense counts
+  uint8_t* refBuf;                 // the scratch buffer a search's reference is assembled in (ref points there, or into the read)
 };
 
 enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
@@ -2386,7 +2387,7 @@ TALC_D void ref_append(uint32_t from, uint32_t to) {
   if (to <= from) return;
   const uint32_t n = to - from;
   if (X.refLen + n > X.C.refCap) { X.overflow |= OVF_SEQ; return; }
-  wave_copy_bytes(X.ref + X.refLen, X.read + from, n, !X.dirRight);
+  wave_copy_bytes(X.refBuf + X.refLen, X.read + from, n, !X.dirRight);
   X.refLen += n;
 }
 
@@ -2425,7 +2426,15 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
     // gap between the start anchor and the target region (:916-918)
     uint32_t gapLen = 0;
     X.refLen = 0;
-    if (X.dirRight) {
+    X.ref = X.refBuf;
+    PROF_BEGIN();
+    if (X.dirRight && whichStart + K <= Rs) {
+      // walking RIGHT the reference — anchor, gap, target region (:916-936) — is a stretch of the read as it stands:
+      // no copy, the search reads it in place (growth order = text order)
+      gapLen = Rs - (whichStart + K);
+      X.ref = const_cast<uint8_t*>(X.read) + whichStart;
+      X.refLen = Re + K - whichStart;
+    } else if (X.dirRight) {
       ref_append(whichStart, whichStart + K);
       if (whichStart + K < Rs) { gapLen = Rs - (whichStart + K); ref_append(whichStart + K, Rs); }
       ref_append(Rs, Re + K);
@@ -2437,6 +2446,7 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
       // which is exactly the reverse of target+gap+anchor (:934-936)
     }
     WSYNC();
+    PROF_END(PF_REFB);
     const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(3 * K));
     if (!pool_shape(PATH_MAXLENGTH)) return false;
     rows_shape();
@@ -2512,6 +2522,7 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
       WSYNC();
       PROF_END(PF_EVALFULL);
       const int nCand = (nOK == X.nFull) ? X.nFull : nOK;   // :955-960
+      PROF_BEGIN();
       if (nCand > 0) {
         // findBestBridge (Trajectory.cpp:282-303)
         int index = 0;
@@ -2536,6 +2547,7 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
           found = true;
         }
       }
+      PROF_END(PF_RESULT);
     }
   }
   return found;
@@ -2559,9 +2571,11 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     // currentGap = extractWeakBorderSequence(seq, whichStart, K, location) (:1035)
     uint32_t gapLen;
     X.refLen = 0;
-    if (X.dirRight) {   // TAIL: anchor + suffix(seq, whichStart+K)
+    X.ref = X.refBuf;
+    if (X.dirRight) {   // TAIL: anchor + suffix(seq, whichStart+K): the read's own tail, read in place
       gapLen = readLen - (whichStart + K);
-      ref_append(whichStart, readLen);
+      X.ref = const_cast<uint8_t*>(X.read) + whichStart;
+      X.refLen = readLen - whichStart;
     } else {            // HEAD: prefix(seq, whichStart) + anchor
       gapLen = whichStart;
       ref_append(whichStart, whichStart + K);
@@ -2651,7 +2665,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.G[1] = make_set(slot + C.o_setB);
   X.ia = 0;
   X.seqPool = slot + C.o_seqPool;
-  X.ref = slot + C.o_ref; X.ancL = (AnchorRec*)(slot + C.o_ancL); X.ancR = (AnchorRec*)(slot + C.o_ancR);
+  X.refBuf = slot + C.o_ref; X.ref = X.refBuf; X.ancL = (AnchorRec*)(slot + C.o_ancL); X.ancR = (AnchorRec*)(slot + C.o_ancR);
   X.ancPos = (uint32_t*)(slot + C.o_ancPos);
   X.fullMeta = (FullMeta*)(slot + C.o_fullMeta); X.fullPool = slot + C.o_fullPoolB;
   X.edgeLong = slot + C.o_edgeLong; X.edgeShort = slot + C.o_edgeShort; X.edgeTmp = slot + C.o_edgeTmp;
