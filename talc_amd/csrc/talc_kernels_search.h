@@ -1063,7 +1063,25 @@ TALC_DN void build_anchors(int side) {
   // registers over this function's calls would each cost a stack save and a restore per call of it
   uint32_t TALC_AS3* const park = (uint32_t TALC_AS3*)g_dp;
   park[l] = regv.x; park[64 + l] = regv.y; park[128 + l] = headv.x;
+  // ... and the region's bases (at most 64 + K - 1 of them), two per lane: an anchor's k-mer is then read from LDS instead
+  // of by a round trip to the read per anchor
+  uint8_t TALC_AS3* const pbase = (uint8_t TALC_AS3*)(park + 192);
+  if (inRegs) {
+    const uint32_t nb = nbKmers + K - 1u;
+    gcu8 rd = (gcu8)X.read + rs;
+    if ((uint32_t)l < nb) pbase[l] = rd[l];
+    if ((uint32_t)l + 64u < nb) pbase[l + 64] = rd[l + 64];
+  }
   LSYNC();
+  // packed k-mer (+ N mask) of the read's position pos (uniform, inside the region): as wave_kmer_at
+  auto kmer_at = [&](uint32_t pos, uint64_t& kmer, uint64_t& nmask) {
+    if (!inRegs) { wave_kmer_at(X.read + pos, (int)K, kmer, nmask); return; }
+    const uint32_t c = ((uint32_t)l < K) ? (uint32_t)pbase[pos - rs + (uint32_t)l] : 0u;
+    nmask = ballot64(((uint32_t)l < K) && (c > 3u));
+    uint64_t v = ((uint32_t)l < K) ? ((uint64_t)(c & 3u) << (2 * (K - 1 - (uint32_t)l))) : 0ull;
+    if (c > 3u) v = 0;
+    kmer = ((uint64_t)wave_or_u32((uint32_t)(v >> 32)) << 32) | wave_or_u32((uint32_t)v);
+  };
   auto run_x = [&](uint32_t pos) -> uint32_t { return park[(pos - rs) & 63u]; };
   auto run_y = [&](uint32_t pos) -> uint32_t { return park[64u + ((pos - rs) & 63u)]; };
 #define RUNX(pos) (inRegs ? run_x(pos) : (clean ? (*(const v2u32 TALC_AS1*)(cr.hits + hbase + ((pos) - rs))).x : COVX(pos)))
@@ -1129,7 +1147,7 @@ TALC_DN void build_anchors(int side) {
       if (nAnc < cap) {
         const uint32_t pf = (uint32_t)lane_get((int)pos, f);
         uint64_t km, nm;
-        wave_kmer_at(X.read + pf, (int)K, km, nm);
+        kmer_at(pf, km, nm);
         const uint32_t recorded = HEADX(base + (uint32_t)f);
         if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, recorded};
         if (nAnc == 0) firstAnchorPos = pf;
@@ -1161,7 +1179,7 @@ TALC_DN void build_anchors(int side) {
           if (nAnc < cap) {
             const uint32_t pf = (uint32_t)lane_get((int)pos, f);
             uint64_t km, nm;
-            wave_kmer_at(X.read + pf, (int)K, km, nm);
+            kmer_at(pf, km, nm);
             const uint32_t cpf = (uint32_t)uni((int)RUNX(pf));
             if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, cpf};
             ++nAnc;
@@ -1175,7 +1193,7 @@ TALC_DN void build_anchors(int side) {
         if (nAnc > 0) goFurther &= (firstAnchorPos != (j + 1));
         if (goFurther) {
           uint64_t km, nm;
-          wave_kmer_at(X.read + (j + 1), (int)K, km, nm);
+          kmer_at(j + 1, km, nm);
           const int degree = dev_out_degree(X.T, MINC, km, nm, 0);
           if (degree > 1) {
             const uint32_t cj1 = (uint32_t)uni((int)RUNX(j + 1));
