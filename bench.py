@@ -594,18 +594,20 @@ def end_to_end_cli(a, w):
         gen_s = time.time() - t0
         sizes = {"dump_bytes": os.path.getsize(dump), "fasta_bytes": os.path.getsize(fa)}
         t0 = time.perf_counter()
-        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1500)
+        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1500, env=dict(os.environ, TALC_TIMING="1"))
         wall = time.perf_counter() - t0
-        timing = None
+        timing, lib_notes = None, []
         for line in p.stderr.decode(errors="replace").splitlines():
             if line.startswith("[talc-timing] "):
                 timing = json.loads(line[len("[talc-timing] "):])
+            elif line.startswith("[talc-lib] "):
+                lib_notes.append(line[len("[talc-lib] "):])
         if p.returncode != 0 or timing is None:
             return {"error": "talc exited with %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-400:])}
         out_bytes = os.path.getsize(outp + ".fa")
         res = {"value": timing["bases"] / wall, "unit": "bases/s", "wall_s": wall,
                "correct_phase_bases_per_s": timing["bases"] / timing["correct_phase_s"] if timing["correct_phase_s"] > 0 else None,
-               "split_s": timing, "output_fa_bytes": out_bytes, "inputs_generated_in_s": gen_s,
+               "split_s": timing, "table_build_detail": lib_notes, "output_fa_bytes": out_bytes, "inputs_generated_in_s": gen_s,
                "what": "talc CLI, child process: read scan + text dump parse + device table build (table_parse_build_s), upload "
                        "incl. filter and walk tables (upload_s), then the pipeline FASTA parse -> H2D -> kernels -> D2H -> 70-column "
                        "FASTA write over two workers per GPU (correct_phase_s; its three busy times overlap); value = read bases / wall_s "

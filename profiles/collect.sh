@@ -16,13 +16,13 @@ export TMPDIR=/tmp
 python3 bench.py --steps 10 --warmup 3 > "$DST/${TAG}_bench.json"
 echo "[collect] bench done"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu --no-h2h --no-paralog > "$DST/${TAG}_bench_under_rocprof.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu --no-h2h --no-paralog --no-e2e > "$DST/${TAG}_bench_under_rocprof.json"
 STATS=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
 cp "$STATS" "$DST/${TAG}_kernel_stats.csv"
 echo "[collect] kernel stats done"
 
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu --no-h2h --no-paralog > "$OUT/pmc_$C.json"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu --no-h2h --no-paralog --no-e2e > "$OUT/pmc_$C.json"
   echo "[collect] pmc $C done"
 done
 

@@ -285,7 +285,13 @@ int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts,
   unsigned long long* dStats = nullptr;
   auto cleanup = [&]() { hipFree(dK); hipFree(dC); hipFree(dSR); hipFree(dSL); hipFree(dStats); };
 #define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); hipFree(dR); hipFree(dL); delete t; return fail(TALC_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  const bool timing = getenv("TALC_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::steady_clock::now(); };
+  auto tsec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const auto td0 = tnow();
   BCHK(hipSetDevice(device));
+  BCHK(hipFree(nullptr));   // (the runtime's own start-up, apart from this call's work in the timing below)
+  const auto td1 = tnow();
   BCHK(hipMalloc((void**)&dR, bytes)); BCHK(hipMalloc((void**)&dL, bytes));
   BCHK(hipMalloc((void**)&dK, std::max<uint64_t>(n, 1) * 8)); BCHK(hipMalloc((void**)&dC, std::max<uint64_t>(n, 1) * 4));
   BCHK(hipMalloc((void**)&dSR, std::max<uint64_t>(n, 1) * 4)); BCHK(hipMalloc((void**)&dSL, std::max<uint64_t>(n, 1) * 4));
@@ -293,6 +299,7 @@ int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts,
   BCHK(hipMemset(dR, 0xFF, bytes)); BCHK(hipMemset(dL, 0xFF, bytes)); BCHK(hipMemset(dStats, 0, 3 * 8));
   if (n) { BCHK(hipMemcpy(dK, kmers, n * 8, hipMemcpyHostToDevice)); BCHK(hipMemcpy(dC, counts, n * 4, hipMemcpyHostToDevice)); }
   BCHK(hipDeviceSynchronize());
+  const auto td2 = tnow();
   if (n) {
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_build_claim, dim3(nb), dim3(256), 0, 0, dR, dL, cap, p->k, dK, dC, n, p->min_count, dSR, dSL);
@@ -305,7 +312,10 @@ int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts,
   unsigned long long st[3];
   BCHK(hipMemcpy(st, dStats, 3 * 8, hipMemcpyDeviceToHost));
 #undef BCHK
+  const auto td3 = tnow();
   cleanup();
+  if (timing) fprintf(stderr, "[talc-lib] device build: runtime start-up %.3f s, allocations + clears + %.0f MB of H2D %.3f s, kernels %.3f s, frees %.3f s\n",
+                      tsec(td0, td1), (double)n * 12 / 1e6, tsec(td1, td2), tsec(td2, td3), tsec(td3, tnow()));
   t->stagedDev = device; t->stR = dR; t->stL = dL;
   t->h.nkmers = st[0]; t->h.nbuckets_right = st[1]; t->h.nbuckets_left = st[2];
   *out = t;
@@ -357,11 +367,19 @@ static int table_build_impl(const char* dump_path, const char* junction_path, co
   std::vector<uint32_t> counts;
   DumpStats ds;
   std::string why;
+  const bool timing = getenv("TALC_TIMING") != nullptr;   // (diagnostic: where a table build's wall time goes, on stderr)
+  const auto tb0 = std::chrono::steady_clock::now();
   if (!parseDumpFile(dump_path, p->k, p->min_count, true, kmers, &counts, nullptr, ds, &why))
     return why.empty() ? fail(TALC_ERR_IO, "cannot open %s", dump_path) : fail(TALC_ERR_INVALID, "%s", why.c_str());
+  const auto tb1 = std::chrono::steady_clock::now();
   talc_table* t = nullptr;
   rc = (device >= 0) ? talc_table_from_arrays_device(kmers.data(), counts.data(), kmers.size(), p, device, &t)
                      : talc_table_from_arrays(kmers.data(), counts.data(), kmers.size(), p, &t);
+  if (timing) {
+    const auto tb2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[talc-lib] dump parse %.3f s (%llu lines), table build on %s %.3f s\n", std::chrono::duration<double>(tb1 - tb0).count(),
+            (unsigned long long)ds.nread, device >= 0 ? "the device (incl. its first HIP call)" : "the host", std::chrono::duration<double>(tb2 - tb1).count());
+  }
   if (rc) return rc;
   std::vector<uint64_t>().swap(kmers);
   std::vector<uint32_t>().swap(counts);

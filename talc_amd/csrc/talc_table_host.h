@@ -225,7 +225,7 @@ static inline bool parseDumpFile(const char* path, uint32_t K, uint32_t minc, bo
     return ok;
   }
   int T = omp_get_max_threads();
-  if (T > 64) T = 64;
+  if (T > 128) T = 128;
   if (size < (1u << 20)) T = 1;
   std::vector<size_t> cut(T + 1, size);
   cut[0] = 0;
@@ -245,7 +245,40 @@ static inline bool parseDumpFile(const char* path, uint32_t K, uint32_t minc, bo
     const char* end = base + cut[t + 1];
     auto isws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
     DumpStats s;
+    {   // the chunk's line count bounds its entries: one allocation per thread instead of a dozen doublings with copies
+      size_t lines = 1;
+      for (const char* q = p; q < end;) { const char* nl = (const char*)memchr(q, '\n', (size_t)(end - q)); if (!nl) break; ++lines; q = nl + 1; }
+      lk[t].reserve(lines);
+      if (counts) lc[t].reserve(lines);
+      if (scounts) ls[t].reserve(lines);
+    }
+    // code of a letter (0..3) or 0x80; the fast path below takes the canonical line of `jellyfish dump -c` — exactly K
+    // letters of ACGT, one blank, one to nine digits, newline — in one forward pass; anything else goes through the
+    // tokeniser, which gives such a line the same answer
+    uint8_t lut[256];
+    for (int i = 0; i < 256; ++i) { const uint8_t c = ascii_to_code((uint8_t)i); lut[i] = c > 3 ? 0x80 : c; }
     while (p < end) {
+      if (p + K + 2 < end) {
+        uint64_t v = 0;
+        uint32_t bad = 0;
+        for (uint32_t i = 0; i < K; ++i) { const uint32_t c = lut[(uint8_t)p[i]]; bad |= c; v = (v << 2) | (c & 3u); }
+        if (!(bad & 0x80u) && (p[K] == ' ' || p[K] == '\t')) {
+          const char* d = p + K + 1;
+          uint32_t cv = 0; int nd = 0;
+          while (d < end && (unsigned)(*d - '0') < 10u && nd < 9) { cv = cv * 10u + (uint32_t)(*d - '0'); ++d; ++nd; }
+          if (nd > 0 && d < end && *d == '\n') {
+            s.nread++;
+            if (!filter || cv >= minc) {
+              if (filter) s.nkept++;
+              lk[t].push_back(v);
+              if (counts) lc[t].push_back(cv);
+              if (scounts) ls[t].push_back((int64_t)cv);
+            }
+            p = d + 1;
+            continue;
+          }
+        }
+      }
       const char* eol = (const char*)memchr(p, '\n', (size_t)(end - p));
       if (!eol) eol = end;
       const char* q = p;
@@ -286,15 +319,18 @@ static inline bool parseDumpFile(const char* path, uint32_t K, uint32_t minc, bo
   kmers.resize(total);
   if (counts) counts->resize(total);
   if (scounts) scounts->resize(total);
-  size_t off = 0;
+  std::vector<size_t> offs(T + 1, 0);
   for (int t = 0; t < T; ++t) {
-    if (!lk[t].empty()) {
-      memcpy(kmers.data() + off, lk[t].data(), lk[t].size() * 8);
-      if (counts) memcpy(counts->data() + off, lc[t].data(), lc[t].size() * 4);
-      if (scounts) memcpy(scounts->data() + off, ls[t].data(), ls[t].size() * 8);
-    }
-    off += lk[t].size();
+    offs[t + 1] = offs[t] + lk[t].size();
     st.nread += lst[t].nread; st.nkept += lst[t].nkept; st.nbad += lst[t].nbad;
+  }
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+  for (int t = 0; t < T; ++t) {   // file order is kept: chunk t's entries follow chunk t-1's
+    if (lk[t].empty()) continue;
+    memcpy(kmers.data() + offs[t], lk[t].data(), lk[t].size() * 8);
+    if (counts) memcpy(counts->data() + offs[t], lc[t].data(), lc[t].size() * 4);
+    if (scounts) memcpy(scounts->data() + offs[t], ls[t].data(), ls[t].size() * 8);
+    std::vector<uint64_t>().swap(lk[t]);
   }
   return true;
 }
