@@ -141,9 +141,10 @@ int talc_table_decolour_repeats(talc_table* t);
 
 uint64_t talc_table_size(const talc_table* t);        /* SR_DBG.size() (main.cpp:237) */
 /* Device memory of one uploaded copy: the two bucket tables and the presence filter, plus the walk tables
- * (2 * capacity * 64 bytes: the fast-forward's lookahead records) once an upload has built them.  An upload
- * builds them when they leave a reserve (64 GB, or a quarter of the device if that is less) to the correction batches
- * (500 M k-mers: 70 GB of buckets + 141 GB of walk records on a 288 GB device);
+ * (2 * capacity * 32 bytes, as much as the bucket tables: the fast-forward's lookahead records) once an upload has
+ * built them; before any upload, the size an upload without walk tables would have.  An upload builds them when they
+ * leave a reserve (64 GB, or a quarter of the device if that is less) to the correction batches
+ * (547 M k-mers: 70 GB of buckets + 70 GB of walk records + 1.4 GB of filter on a 288 GB device);
  * the environment variable TALC_WALK=0 turns them off, TALC_WALK=1 makes their allocation mandatory. */
 uint64_t talc_table_device_bytes(const talc_table* t);
 
@@ -195,7 +196,8 @@ int talc_batch_create(talc_ctx* c, const char* bases, const uint64_t* offsets, u
 void talc_batch_destroy(talc_batch* b);
 
 /* Read::reCoverage (Read.cpp:174-195) for every read of the batch: the k-mer probe kernel.
- * Results stay on the device; talc_batch_fetch_coverage copies them out. */
+ * Results stay on the device — as the hits only: a bitmap word per 64 positions plus the {count, colour} pairs of the
+ * k-mers that are in the table; talc_batch_fetch_coverage expands them into the reference's dense vector. */
 int talc_batch_coverage(talc_ctx* c, talc_batch* b);
 /* counts/jcounts: one entry per k-mer, reads concatenated (read r contributes max(0,L_r-K+1)
  * entries); kmer_offsets[n_reads+1] (may be NULL); n_in_kmers[n_reads] = #{count > min_count}
