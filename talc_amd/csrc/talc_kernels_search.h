@@ -2492,6 +2492,9 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
       // per full path: score (edit distance), idscore, ok, new right anchor, cut (off,len)
       // stored in gScores (score), gDists (idscore) and gKept (ok | cutLen<<1), ranc updated in meta
       PROF_BEGIN();
+      FullMeta lone = FullMeta();
+      uint32_t loneFlags = 0;
+      unsigned long long loneIdBits = 0;
       for (int t = 0; t < X.nFull; ++t) {
         const FullMeta fm = X.fullMeta[t];
         const uint8_t* ps = X.fullPool + fm.off;
@@ -2531,29 +2534,43 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
           if (ranc + 2 * K - fm.len <= limit2) ranc = ranc + 2 * K - fm.len;
           else ok = false;
         } else ok = false;
-        if (l == 0) {
+        if (X.nFull == 1) {   // a lone candidate: its figures stay in (scalar) registers, no trip through memory
+          lone = fm; lone.ranc = (int32_t)ranc;
+          loneFlags = (ok ? 1u : 0u) | (cutLen << 1);
+          loneIdBits = uni64((unsigned long long)__double_as_longlong(idv));
+        } else if (l == 0) {
           X.gScores[t] = score; X.gDists[t] = idv; X.gKept[t] = (ok ? 1u : 0u) | (cutLen << 1);
           X.fullMeta[t].ranc = (int32_t)ranc;
         }
         nOK += ok ? 1 : 0;
       }
-      WSYNC();
+      if (X.nFull > 1) WSYNC();
       PROF_END(PF_EVALFULL);
       const int nCand = (nOK == X.nFull) ? X.nFull : nOK;   // :955-960
       PROF_BEGIN();
       if (nCand > 0) {
         // findBestBridge (Trajectory.cpp:282-303)
-        int index = 0;
-        for (int i = 1; i < nCand; ++i) if (X.gScores[i] > X.gScores[index]) index = i;
-        const int first = index;
-        for (int i = first + 1; i < nCand; ++i)
-          if (X.gScores[i] == X.gScores[first] && X.fullMeta[i].dist > X.fullMeta[index].dist) index = i;
-        const FullMeta bm = X.fullMeta[index];
-        const uint32_t flags = X.gKept[index];
+        FullMeta bm;
+        uint32_t flags;
+        double bestId;
+        if (X.nFull == 1) {
+          bm.off = (uint32_t)uni((int)lone.off); bm.len = (uint32_t)uni((int)lone.len); bm.lanc = uni(lone.lanc); bm.ranc = uni(lone.ranc); bm.dist = 0.0;
+          flags = (uint32_t)uni((int)loneFlags);
+          bestId = __longlong_as_double((long long)loneIdBits);
+        } else {
+          int index = 0;
+          for (int i = 1; i < nCand; ++i) if (X.gScores[i] > X.gScores[index]) index = i;
+          const int first = index;
+          for (int i = first + 1; i < nCand; ++i)
+            if (X.gScores[i] == X.gScores[first] && X.fullMeta[i].dist > X.fullMeta[index].dist) index = i;
+          bm = X.fullMeta[index];
+          flags = X.gKept[index];
+          bestId = X.gDists[index];
+        }
         // a path whose cutAnchors failed has an empty sequence (truncSeq stays empty)
         const uint32_t bestLen = (flags & 1u) ? (flags >> 1) : 0u;
         const double diff = (double)X.weakLen - (double)bestLen;
-        if (((diff < X.weakLen * 0.05) || ((X.weakLen < 6) & (bestLen < 6))) & (X.gDists[index] >= P.MIN_INNER)) {
+        if (((diff < X.weakLen * 0.05) || ((X.weakLen < 6) & (bestLen < 6))) & (bestId >= P.MIN_INNER)) {
           X.Le = (uint32_t)bm.lanc;
           X.Rs = (uint32_t)bm.ranc;
           // weak sequence := path without its two anchors, stored in natural orientation

@@ -700,6 +700,11 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   }
   const int eEnd = (toLevel >= 0) ? min(x, toLevel) : x;
   unsigned long long work = 0;
+  // the far corner lies on diagonal qlen - dlen: outside the band (an edge's reference is far longer than its Trail) it can
+  // never be reached, and the level loop need not look for it
+  const int kc = qlen - dlen;
+  const bool cornerInBand = (kc >= kmin) & (kc <= kmax);
+  int eLast = eStart - 1;
   for (int e = eStart; e <= eEnd && !cornerHit; ++e) {
     int rotR[NR], rotL[NR];
 #pragma unroll
@@ -729,10 +734,16 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
       if (moved[s]) { F[s] = b[s]; E[s] = e; }
-      hit |= ballot64(F[s] == corner);
+      if (cornerInBand) hit |= ballot64(F[s] == corner);
     }
-    work += (unsigned long long)min(nd, 2 * e + 1);
     if (hit != 0ull) { cornerHit = true; cornerE = e; }
+    eLast = e;
+  }
+  if (eLast >= eStart) {   // the levels' diagonals, counted once: sum over e = eStart..eLast of min(nd, 2 e + 1)
+    const int eh = min(eLast, (nd - 1) / 2);   // levels whose 2 e + 1 diagonals all fit the band
+    const int lo = max(eh, eStart - 1);
+    if (eh >= eStart) work += (unsigned long long)((eh - eStart + 1) * (eh + eStart + 1));
+    if (eLast > lo) work += (unsigned long long)((eLast - lo) * nd);
   }
   cells += work;
   WPROF_ADD(1, _t1);
