@@ -867,7 +867,9 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
 }
 
 // ------------------------------------------------------------------ trace helpers
-TALC_D void trace_rec(int kind, int a, int b, int c, int d, double x, const uint8_t* s, uint32_t slen, bool rev) {
+// (the debug hook's code is real, cold calls: inlined at its dozen sites it was a tenth of k_search's instructions and
+//  carried forty of its spill slots — for a path no production launch takes)
+TALC_DNC void trace_rec(int kind, int a, int b, int c, int d, double x, const uint8_t* s, uint32_t slen, bool rev) {
   if (!X.tracing) return;
   WSYNC();
   if (lane_id() == 0) {
@@ -2482,7 +2484,7 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
       nCur = uni(step_bridge(nCur, len, stepCounter));
       PROF_END2(PF_STEPB);
       ++len;
-      if (X.tracing && X.trace.steps) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
+      if (uni((int)(X.tracing && X.trace.steps))) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
     }
     if (X.overflow) return false;
     if (X.nFull > 0) {
@@ -2642,7 +2644,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
       nCur = uni(step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop));
       PROF_END2(PF_STEPE);
       ++len;
-      if (X.tracing && X.trace.steps)
+      if (uni((int)(X.tracing && X.trace.steps)))
         trace_rec(TR_STEP, (int)stepCounter, nCur, X.nEdges, xdrop, 0.0, nullptr, 0, false);
     }
     if (X.overflow) return false;
@@ -2670,7 +2672,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
   return found;
 }
 
-TALC_D void trace_search() {
+TALC_DNC void trace_search_cold() {
   if (!X.tracing) return;
   const int locRef = X.location == LOC_HEAD ? 0 : X.location == LOC_INNER ? 1 : 2;   // Location enum of the reference
   const int nL = (X.location == LOC_HEAD) ? 0 : X.nAncL, nR = (X.location == LOC_TAIL) ? 0 : X.nAncR;
@@ -2802,9 +2804,9 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
           // (the LEFT attempt after a failed RIGHT one starts from the same two regions — a failed search changes
           //  neither — so anchorLEFTHandSide / anchorRIGHTHandSide, Explorer.cpp:239-240, would return the lists again)
           if (attempt == 0) { build_anchors(0); build_anchors(1); }
-          trace_search();
+          if (uni((int)X.tracing)) trace_search_cold();
           PROF_BEGIN2(); success = search_bridge(wo, wl, weakUsed); PROF_END2(PF_SRCHB);
-          if (X.tracing) {
+          if (uni((int)X.tracing)) {
             if (success) trace_rec(TR_RESULT, 1, 1, (int)X.Le, (int)X.Rs, 0.0, X.weak + wo, wl, false);
             else trace_rec(TR_RESULT, 1, 0, (int)X.regE[reg], (int)X.regS[reg + 1], 0.0, X.read + X.regE[reg] + K, X.weakLen, false);
           }
@@ -2822,9 +2824,9 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         X.weakLen = X.Rs;
         X.nAncL = 0;
         build_anchors(1);
-        trace_search();
+        if (uni((int)X.tracing)) trace_search_cold();
         PROF_BEGIN2(); headCorr = search_edge(headOff, headCLen, weakUsed); PROF_END2(PF_SRCHE);
-        if (X.tracing) {
+        if (uni((int)X.tracing)) {
           if (headCorr) trace_rec(TR_RESULT, 0, 1, 0, (int)X.Rs, 0.0, X.weak + headOff, headCLen, false);
           else trace_rec(TR_RESULT, 0, 0, 0, (int)X.regS[0], 0.0, X.read, X.weakLen, false);
         }
@@ -2839,9 +2841,9 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         X.weakLen = L - (X.Le + K);
         X.nAncR = 0;
         build_anchors(0);
-        trace_search();
+        if (uni((int)X.tracing)) trace_search_cold();
         PROF_BEGIN2(); tailCorr = search_edge(tailOff, tailCLen, weakUsed); PROF_END2(PF_SRCHE);
-        if (X.tracing) {
+        if (uni((int)X.tracing)) {
           if (tailCorr) trace_rec(TR_RESULT, 2, 1, (int)X.Le, 0, 0.0, X.weak + tailOff, tailCLen, false);
           else trace_rec(TR_RESULT, 2, 0, (int)X.regE[R - 1], 0, 0.0, X.read + X.regE[R - 1] + K, X.weakLen, false);
         }
