@@ -1254,7 +1254,10 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 // x grows by 2 per scoring, Explorer.cpp:713) — a function of its own, entered by a tail call, so that the registers of
 // its eight-diagonals-per-lane phase (and the callee-saved ones it has to save) are paid by the few calls that get that
 // far, not by every extension.
-template <bool WIDE>
+// MODE 0: the band fits one diagonal per lane (x up to 31: two thirds of all calls, and the instance the hot path's
+// registers and instruction cache see); 1: phases of one, two and four diagonals per lane (up to 255 diagonals);
+// 2: WIDE, with an eight-wide phase behind them (up to 511)
+template <int MODE>
 TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
                                        bool withScore) {
   PROF_DECL;
@@ -1276,7 +1279,7 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
     uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
     // furthest-reaching wavefronts, 1 / 2 / 4 diagonals per lane (x up to 31 / 63 / 127)
     const int ndiagonals = min(max(xdrop, 0), qlen) + min(max(xdrop, 0), dlen) + 1;
-    if (WIDE) {
+    if (MODE == 2) {
       // in phases (WfaPhase): levels 0..31 one diagonal per lane, 32..63 two, 64..127 four, the rest eight.  (A 500-base
       // edge ends near x = 210; without the eight-wide phase its last forty scorings per anchor fell back to the
       // anti-diagonal sweep — most of the 40 ms of the heaviest reads of a batch, which is what the launch waits for.)
@@ -1296,8 +1299,8 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
         }
       }
     }
-    else if (ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
-    else if (ndiagonals <= 255) {   // (the hand-over state lives in the HBM DP arrays: make_caps keeps them at 2048 ints or more)
+    else if (MODE == 0 && ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (MODE == 1 && ndiagonals <= 255) {   // (the hand-over state lives in the HBM DP arrays: make_caps keeps them at 2048 ints or more)
       // in phases (WfaPhase): levels 0..31 one diagonal per lane, 32..63 two, the rest four
       int* mem = X.dpG + 2ull * X.C.dpCap + 256;   // (past the flags of the multi-x run)
       WfaPhase ph{-1, 31, mem, mem + 512};
@@ -1348,7 +1351,10 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
 }
 
 TALC_DNC SeedExt seed_and_extension_wide(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
-  return seed_and_extension_body<true>(ref, refLen, cand, candLen, xdrop, withScore);
+  return seed_and_extension_body<2>(ref, refLen, cand, candLen, xdrop, withScore);
+}
+TALC_DN SeedExt seed_and_extension_mid(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
+  return seed_and_extension_body<1>(ref, refLen, cand, candLen, xdrop, withScore);
 }
 TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
   {   // more than 255 diagonals (and a stage that takes the segments): the wide instance
@@ -1358,9 +1364,10 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
     if (qlen > 0 && dlen > 0) {
       const int nd = min(x, qlen) + min(x, dlen) + 1;
       if (nd > 255 && nd <= 511) [[clang::musttail]] return seed_and_extension_wide(ref, refLen, cand, candLen, xdrop, withScore);
+      if (nd > 63 && nd <= 255) [[clang::musttail]] return seed_and_extension_mid(ref, refLen, cand, candLen, xdrop, withScore);
     }
   }
-  return seed_and_extension_body<false>(ref, refLen, cand, candLen, xdrop, withScore);
+  return seed_and_extension_body<0>(ref, refLen, cand, candLen, xdrop, withScore);
 }
 
 // getSeedAndExtension without the score (the form findStopPosition uses) from a given extension (extCols on the
@@ -1733,6 +1740,34 @@ TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_)
   }
 }
 
+// A child of the generic step whose tip is an aim (checkAims, Trail.cpp:273-285): recordBridge (Explorer.cpp:1097-1101).
+// Returns false when the recorded path is longer than the reference and the Trail ends there (:579-582).  A real, cold
+// call: nearly every step onto an aim is taken by the fast-forward, and this body sat in the middle of the step's loop.
+TALC_DNC bool record_bridge_at_aim(int nNew_, int hit_, int len_, uint64_t km2, uint64_t nm2) {
+  const int nNew = uni(nNew_), hit = uni(hit_), len = uni(len_);
+  const int l = lane_id();
+  const int ib = X.ia ^ 1;
+  const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
+  const int apos = (hit < AIMS_LDS) ? (int)g_aimPos[hit] : (int)aims[hit].pos;
+  TrailRec ch = tr_get(ib, nNew);
+  if (X.dirRight) ch.ranc = apos; else ch.lanc = apos;
+  if (l == 0) tr_put(ib, nNew, ch);
+  WSYNC();   // also publishes the base lane 0 has just appended
+  const uint32_t clen = (uint32_t)len + 1;
+  if (X.nFull >= (int)X.C.fullCap) X.overflow |= OVF_FULLPATHS;
+  else if (X.fullUsed + clen > X.C.fullPool) X.overflow |= OVF_FULLPOOL;
+  else {
+    wave_copy_bytes(X.fullPool + X.fullUsed, X.seqPool + (uint64_t)ch.buf * X.C.seqCap, clen, false);
+    if (l == 0) X.fullMeta[X.nFull] = FullMeta{X.fullUsed, clen, ch.lanc, ch.ranc, ch.dist / ((double)clen + 0.01)};
+    X.fullUsed += (clen + 15u) & ~15u;
+    X.nFull++;
+    WSYNC();
+  }
+  bloom_query_insert(uni64(km2), uni64(nm2));   // keep the filter a superset of every live Trail's k-mers
+  if (clen > X.refLen) { pool_free((uint32_t)uni((int)ch.buf)); return false; }
+  return true;
+}
+
 TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   PROF_DECL;
   const DevParams& P = X.P;
@@ -1788,24 +1823,7 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
         }
         PROF_END(PF_AIMS);
         if (hit >= 0) {
-          const int apos = (hit < AIMS_LDS) ? (int)g_aimPos[hit] : (int)aims[hit].pos;
-          TrailRec ch = tr_get(ib, nNew);
-          if (X.dirRight) ch.ranc = apos; else ch.lanc = apos;
-          if (l == 0) tr_put(ib, nNew, ch);
-          WSYNC();   // also publishes the base lane 0 has just appended
-          // recordBridge (Explorer.cpp:1097-1101)
-          const uint32_t clen = (uint32_t)len + 1;
-          if (X.nFull >= (int)X.C.fullCap) X.overflow |= OVF_FULLPATHS;
-          else if (X.fullUsed + clen > X.C.fullPool) X.overflow |= OVF_FULLPOOL;
-          else {
-            wave_copy_bytes(X.fullPool + X.fullUsed, X.seqPool + (uint64_t)ch.buf * X.C.seqCap, clen, false);
-            if (l == 0) X.fullMeta[X.nFull] = FullMeta{X.fullUsed, clen, ch.lanc, ch.ranc, ch.dist / ((double)clen + 0.01)};
-            X.fullUsed += (clen + 15u) & ~15u;
-            X.nFull++;
-            WSYNC();
-          }
-          bloom_query_insert(km2, nm2);   // keep the filter a superset of every live Trail's k-mers
-          if (clen > X.refLen) { pool_free(ch.buf); continue; }   // :579-582 pop_back
+          if (!uni((int)record_bridge_at_aim(nNew, hit, len, km2, nm2))) continue;   // :579-582 pop_back
           ++nNew;
         } else {
           PROF_BEGIN();
@@ -2421,6 +2439,18 @@ TALC_D AnchorRec uni_anchor(const AnchorRec* p) {
   return r;
 }
 
+// findBestBridge (Trajectory.cpp:282-303) over several scored candidates (gScores / fullMeta): the first best score,
+// then the largest distance among the later candidates that tie with it.  (Cold: config 2 never records two bridges.)
+TALC_DNC int find_best_bridge(int nCand_) {
+  const int nCand = uni(nCand_);
+  int index = 0;
+  for (int i = 1; i < nCand; ++i) if (X.gScores[i] > X.gScores[index]) index = i;
+  const int first = index;
+  for (int i = first + 1; i < nCand; ++i)
+    if (X.gScores[i] == X.gScores[first] && X.fullMeta[i].dist > X.fullMeta[index].dist) index = i;
+  return index;
+}
+
 // Explorer::searchBridge (Explorer.cpp:868-989) after initializeINNER(…, direction)
 TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
   PROF_DECL; PROF_DECL2;
@@ -2560,11 +2590,7 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
           flags = (uint32_t)uni((int)loneFlags);
           bestId = __longlong_as_double((long long)loneIdBits);
         } else {
-          int index = 0;
-          for (int i = 1; i < nCand; ++i) if (X.gScores[i] > X.gScores[index]) index = i;
-          const int first = index;
-          for (int i = first + 1; i < nCand; ++i)
-            if (X.gScores[i] == X.gScores[first] && X.fullMeta[i].dist > X.fullMeta[index].dist) index = i;
+          const int index = uni(find_best_bridge(nCand));
           bm = X.fullMeta[index];
           flags = X.gKept[index];
           bestId = X.gDists[index];
