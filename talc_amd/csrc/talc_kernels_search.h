@@ -866,6 +866,39 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
   if (!haveLcs) lcsLen = (int)(uint32_t)(packed >> 32);
 }
 
+// The question a LONE bridge candidate is asked (Explorer.cpp:973: is its identity with the reference at least
+// MIN_INNER): does the LCS of the two sequences reach acceptLcs?  Returns acceptLcs or the exact LCS, as edit_and_lcs
+// with needEdit = false does — through the two narrow wavefront instances only, which settle nearly every gap of a
+// unique-sequence graph; anything else goes to edit_and_lcs.  (A function of its own: edit_and_lcs carries six wavefront
+// instances and the bit-vector routines, 7000 instructions, and this is the call the bridge search makes per gap.)
+TALC_DN int lcs_reaches(const uint8_t* a_, int la, const uint8_t* b_, int lb, int acceptLcs_) {
+  la = uni(la); lb = uni(lb);
+  const int acceptLcs = uni(acceptLcs_);
+  const uint8_t* a = uni_ptr(a_); const uint8_t* b = uni_ptr(b_);
+  if (la < lb) { const uint8_t* t = a; a = b; b = t; int tl = la; la = lb; lb = tl; }
+  constexpr int STAGE = 3 * LDS_DP_CAP * 4;
+  const int qpad = (la + 16) & ~7;
+  const int lo = la - lb;
+  if (acceptLcs > 0 && lb > 0 && qpad + lb + 16 <= STAGE && lo <= 63 && la <= 440) {
+    uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
+    stage_copy(stage, (gcu8)a, la);
+    stage_copy(stage + qpad, (gcu8)b, lb);
+    if (lane_id() == 0) { stage[la] = 0xF0; stage[qpad + lb] = 0xF1; }
+    WSYNC();
+    unsigned long long ncells = 0;
+    int d = -1;
+    if (lo <= 31 && la <= 220) d = wave_wfa_global<1, false>(stage, qpad, la, lb, ncells, 2 * acceptLcs);
+    if (d == -1) d = wave_wfa_global<2, false>(stage, qpad, la, lb, ncells, 2 * acceptLcs);
+    X.cells += ncells;
+    WSYNC();
+    if (d >= 0) return (la + lb - d) >> 1;
+    if (d == -2) return acceptLcs;
+  }
+  int es = 0, lcs = 0;
+  edit_and_lcs(a, la, b, lb, es, lcs, false, acceptLcs);
+  return uni(lcs);
+}
+
 // ------------------------------------------------------------------ trace helpers
 // (the debug hook's code is real, cold calls: inlined at its dozen sites it was a tenth of k_search's instructions and
 //  carried forty of its spill slots — for a path no production launch takes)
@@ -1857,10 +1890,10 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
 // Explorer::scoreEdges (Explorer.cpp:709-740) on the new set (n trails of length len); survivors
 // are compacted in place; returns their number
 // (ib = the Trail set to score: the new set of a generic step, or the current set when the fast-forward took the step)
+TALC_DNC int score_edges_multi(int ib_, int n_, int len_, int& xdrop_);
 TALC_D int score_edges(int ib_, int n_, int len_, int& xdrop_) {
   const int n = uni(n_), len = uni(len_);
   if (n == 0) return 0;
-  const int l = lane_id();
   const int ib = uni(ib_);
   const int xdrop = uni(xdrop_) + 2;
   if (n == 1) {
@@ -1870,6 +1903,16 @@ TALC_D int score_edges(int ib_, int n_, int len_, int& xdrop_) {
     if (!ok) { record_edge(ib, 0, len); pool_free((uint32_t)uni((int)tr_buf(ib, 0))); return 0; }
     return 1;
   }
+  int xd = xdrop - 2;
+  const int kept = uni(score_edges_multi(ib, n, len, xd));
+  xdrop_ = uni(xd);
+  return kept;
+}
+// ... with several live Trails (a real, cold call: the edge loop of a unique-sequence graph never gets here)
+TALC_DNC int score_edges_multi(int ib_, int n_, int len_, int& xdrop_) {
+  const int n = uni(n_), len = uni(len_), ib = uni(ib_);
+  const int l = lane_id();
+  const int xdrop = uni(xdrop_) + 2;
   int new_xdrop = 0;
   int nSel = 0;
   // trash paths are only needed when nobody survives: remember them by flag in gKept
@@ -2554,7 +2597,10 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
           needed = ok1 && ((diff1 < X.weakLen * 0.05) || ((X.weakLen < 6) & (bestLen1 < 6)));
         }
         es = 0; lcs = 0;
-        if (uni((int)needed)) edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs, X.nFull > 1, accept);
+        if (uni((int)needed)) {
+          if (X.nFull == 1 && accept > 0) lcs = lcs_reaches(X.ref, (int)X.refLen, ps, (int)fm.len, accept);
+          else edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs, X.nFull > 1, accept);
+        }
         score = (double)es;
         idv = (double)lcs / (double)max(X.refLen, fm.len);
         // cutAnchors INNER (Trajectory.cpp:176-197)
