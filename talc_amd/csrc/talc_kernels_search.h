@@ -1801,6 +1801,8 @@ TALC_DNC bool record_bridge_at_aim(int nNew_, int hit_, int len_, uint64_t km2, 
   return true;
 }
 
+// (inlined at its one call site: as a real call — tried again in round 3, after step_edge had become one — the 4.3 M
+//  generic bridge steps of a config-2 launch pay for a prologue each: 40.7 -> 42.5 ms)
 TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   PROF_DECL;
   const DevParams& P = X.P;
@@ -1952,7 +1954,9 @@ TALC_DNC int score_edges_multi(int ib_, int n_, int len_, int& xdrop_) {
 }
 
 // Explorer::oneMoreStepInTheDark (Explorer.cpp:615-687)
-TALC_D int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, int& xdrop) {
+// (a real call since round 3: the generic step is 4 % of an edge's steps, and its body in the middle of search_edge's
+//  loop cost the single-Trail iterations around it more than the call costs the generic ones: 41.4 -> 40.7 ms)
+TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, int& xdrop) {
   PROF_DECL;
   const DevParams& P = X.P;
   const int l = lane_id();
