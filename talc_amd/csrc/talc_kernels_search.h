@@ -175,6 +175,12 @@ struct TraceRec { int32_t kind; int32_t a, b, c, d; double x; uint32_t soff, sle
 struct TraceBuf { TraceRec* recs; uint32_t* nrec; uint32_t cap; uint8_t* pool; uint32_t* npool; uint32_t poolCap; int steps; };
 enum { TR_REGION = 1, TR_THRESHOLD = 2, TR_SEARCH = 3, TR_ANCHOR = 4, TR_RESULT = 5, TR_STEP = 6 };
 
+// wave_copy_bytes as a real call: two dozen inlined copies of its loop were a quarter of k_search's instructions, and
+// every one of them waits on a global round trip anyway (a leaf with a handful of registers: nothing to save)
+TALC_DN void copy_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, bool rev) {
+  wave_copy_bytes(uni_ptr(dst), uni_ptr(src), (uint32_t)uni((int)n), uni((int)rev) != 0);
+}
+
 // ------------------------------------------------------------------ small wave helpers on reads
 // packed natural-orientation k-mer (+ N mask) of s[0..K): lanes 0..K-1 load one base each
 TALC_D void wave_kmer_at(const uint8_t* __restrict__ s, int K, uint64_t& kmer, uint64_t& nmask) {
@@ -1558,15 +1564,15 @@ TALC_DN void record_edge(int set_, int t_, int len0_) {
     // prefix(path, pos) walking RIGHT / suffix(path, pos) walking LEFT == growth-order prefix of length S+ext(path)
     newLen = (uint32_t)cur.lenRefExt;   // `reference` of findStopPosition is the path here
     if (newLen > X.C.edgeCap) { X.overflow |= OVF_SEQ; return; }
-    wave_copy_bytes(tmp, path, newLen, false);
+    copy_bytes(tmp, path, newLen, false);
   } else {
     // path followed by the rest of the reference beyond the stop position
     const uint32_t from = (uint32_t)cur.lenRefExt;
     const uint32_t rest = (uint32_t)refLen > from ? (uint32_t)refLen - from : 0;
     newLen = (uint32_t)len + rest;
     if (newLen > X.C.edgeCap) { X.overflow |= OVF_SEQ; return; }
-    wave_copy_bytes(tmp, path, (uint32_t)len, false);
-    wave_copy_bytes(tmp + len, X.ref + from, rest, false);
+    copy_bytes(tmp, path, (uint32_t)len, false);
+    copy_bytes(tmp + len, X.ref + from, rest, false);
   }
   WSYNC();
   // cutAnchors HEAD/TAIL (Trajectory.cpp:168-175): drop the anchor (growth-order front); never fails
@@ -1585,7 +1591,7 @@ TALC_DN void record_edge(int set_, int t_, int len0_) {
     best.have = true; best.score = score; best.dist = dist; best.idscore = idscore; best.len = cutLen;
     best.lanc = lanc; best.ranc = ranc;
     X.best2[bi] = best;
-    wave_copy_bytes(bestSeq, tmp + cutFrom, cutLen, false);
+    copy_bytes(bestSeq, tmp + cutFrom, cutLen, false);
     WSYNC();
   }
   PROF_END(PF_EDGEMISC);
@@ -1790,7 +1796,7 @@ TALC_DNC bool record_bridge_at_aim(int nNew_, int hit_, int len_, uint64_t km2, 
   if (X.nFull >= (int)X.C.fullCap) X.overflow |= OVF_FULLPATHS;
   else if (X.fullUsed + clen > X.C.fullPool) X.overflow |= OVF_FULLPOOL;
   else {
-    wave_copy_bytes(X.fullPool + X.fullUsed, X.seqPool + (uint64_t)ch.buf * X.C.seqCap, clen, false);
+    copy_bytes(X.fullPool + X.fullUsed, X.seqPool + (uint64_t)ch.buf * X.C.seqCap, clen, false);
     if (l == 0) X.fullMeta[X.nFull] = FullMeta{X.fullUsed, clen, ch.lanc, ch.ranc, ch.dist / ((double)clen + 0.01)};
     X.fullUsed += (clen + 15u) & ~15u;
     X.nFull++;
@@ -2357,7 +2363,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
       if (X.nFull >= (int)X.C.fullCap) X.overflow |= OVF_FULLPATHS;
       else if (X.fullUsed + clen > X.C.fullPool) X.overflow |= OVF_FULLPOOL;
       else {
-        wave_copy_bytes(X.fullPool + X.fullUsed, (const uint8_t*)seq, clen, false);
+        wave_copy_bytes(X.fullPool + X.fullUsed, (const uint8_t*)seq, clen, false);   // (inline: the fast-forward stays a leaf)
         if (l == 0) X.fullMeta[X.nFull] = FullMeta{X.fullUsed, clen, lanc, ranc, dist / ((double)clen + 0.01)};
         X.fullUsed += (clen + 15u) & ~15u;
         X.nFull++;
@@ -2424,7 +2430,7 @@ TALC_D void init_first_trail(const AnchorRec& a, const AnchorRec* inList, bool w
   (void)inList;
   pool_reset();
   const uint32_t b0 = (uint32_t)pool_alloc();
-  wave_copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
+  copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
   // a bridge search's first buffer starts without a kept alignment row.  Every other buffer a search hands out gets its
   // record from row_copy (branch_copy, garden), so no record is ever read that this search has not written: the stamps in
   // a record's end words (row_covered) are a second line of defence, not the guarantee.
@@ -2472,7 +2478,7 @@ TALC_D void ref_append(uint32_t from, uint32_t to) {
   if (to <= from) return;
   const uint32_t n = to - from;
   if (X.refLen + n > X.C.refCap) { X.overflow |= OVF_SEQ; return; }
-  wave_copy_bytes(X.refBuf + X.refLen, X.read + from, n, !X.dirRight);
+  copy_bytes(X.refBuf + X.refLen, X.read + from, n, !X.dirRight);
   X.refLen += n;
 }
 
@@ -2653,7 +2659,7 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
           X.Rs = (uint32_t)bm.ranc;
           // weak sequence := path without its two anchors, stored in natural orientation
           if (weakUsed + bestLen > X.C.weakPool) { X.overflow |= OVF_WEAKPOOL; return false; }
-          if (bestLen) wave_copy_bytes(X.weak + weakUsed, X.fullPool + bm.off + K, bestLen, !X.dirRight);
+          if (bestLen) copy_bytes(X.weak + weakUsed, X.fullPool + bm.off + K, bestLen, !X.dirRight);
           weakOutOff = weakUsed; weakOutLen = bestLen;
           weakUsed += bestLen;
           WSYNC();
@@ -2738,7 +2744,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
     if (((diff < X.weakLen * 0.05) || ((X.weakLen < 6) & (w.len < 6))) & (w.idscore >= minScore)) {
       found = true;
       if (weakUsed + w.len > X.C.weakPool) { X.overflow |= OVF_WEAKPOOL; return false; }
-      if (w.len) wave_copy_bytes(X.weak + weakUsed, wseq, w.len, !X.dirRight);
+      if (w.len) copy_bytes(X.weak + weakUsed, wseq, w.len, !X.dirRight);
       weakOutOff = weakUsed; weakOutLen = w.len;
       weakUsed += w.len;
       if (X.location == LOC_TAIL) X.Le = w.lanc; else X.Rs = w.ranc;
@@ -2841,7 +2847,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
 
     if (st.status != TALC_READ_CORRECTED || st.overflow) {
       // not corrected: pass the (encoded) read through (main.cpp:310 writes mySeqs[r] unchanged)
-      wave_copy_bytes(out, X.read, L, false);
+      copy_bytes(out, X.read, L, false);
       if (l == 0) { state[r].outLen = L; }
       continue;
     }
@@ -2933,7 +2939,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     if (l == 0) state[r].pfSteps = (uint32_t)X.steps;
 #endif
     if (X.overflow) {
-      wave_copy_bytes(out, X.read, L, false);
+      copy_bytes(out, X.read, L, false);
       if (l == 0) { state[r].outLen = L; state[r].overflow = X.overflow; }
       continue;
     }
@@ -2954,28 +2960,28 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     }
     total += tailPresent ? (tailCorr ? tailCLen : tailLen) : 0;
     if (total > outCap) {
-      wave_copy_bytes(out, X.read, L, false);
+      copy_bytes(out, X.read, L, false);
       if (l == 0) { state[r].outLen = L; state[r].overflow = OVF_OUT; }
       continue;
     }
     uint32_t pos = 0;
     PROF_BEGIN2();
     if (headPresent) {
-      if (headCorr) { wave_copy_bytes(out + pos, X.weak + headOff, headCLen, false); pos += headCLen; }
-      else { wave_copy_bytes(out + pos, X.read, headLen, false); pos += headLen; }
+      if (headCorr) { copy_bytes(out + pos, X.weak + headOff, headCLen, false); pos += headCLen; }
+      else { copy_bytes(out + pos, X.read, headLen, false); pos += headLen; }
     }
     for (uint32_t i = 0; i < R; ++i) {
       const uint32_t s = X.regS[i], e = X.regE[i];
       const uint32_t sl = e + K - s;
-      wave_copy_bytes(out + pos, X.read + s, sl, false); pos += sl;
+      copy_bytes(out + pos, X.read + s, sl, false); pos += sl;
       if (i + 1 < R) {
-        if (X.wLen[i] != 0xFFFFFFFFu) { wave_copy_bytes(out + pos, X.weak + X.wOff[i], X.wLen[i], false); pos += X.wLen[i]; }
-        else if (X.regS[i + 1] > e + K) { const uint32_t wl = X.regS[i + 1] - (e + K); wave_copy_bytes(out + pos, X.read + e + K, wl, false); pos += wl; }
+        if (X.wLen[i] != 0xFFFFFFFFu) { copy_bytes(out + pos, X.weak + X.wOff[i], X.wLen[i], false); pos += X.wLen[i]; }
+        else if (X.regS[i + 1] > e + K) { const uint32_t wl = X.regS[i + 1] - (e + K); copy_bytes(out + pos, X.read + e + K, wl, false); pos += wl; }
       }
     }
     if (tailPresent) {
-      if (tailCorr) { wave_copy_bytes(out + pos, X.weak + tailOff, tailCLen, false); pos += tailCLen; }
-      else { wave_copy_bytes(out + pos, X.read + (L - tailLen), tailLen, false); pos += tailLen; }
+      if (tailCorr) { copy_bytes(out + pos, X.weak + tailOff, tailCLen, false); pos += tailCLen; }
+      else { copy_bytes(out + pos, X.read + (L - tailLen), tailLen, false); pos += tailLen; }
     }
     {   // Read.cpp:423 on the regions as correct2 leaves them
       unsigned long long part = 0;
