@@ -1285,7 +1285,7 @@ TALC_DNC unsigned long long xdrop_sweep(const uint8_t* q, int qlen_, const uint8
 }
 
 // ------------------------------------------------------------------ getSeedAndExtension (Trail.cpp:341-437)
-struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extRef, extCand; };
+struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extRef, extCand; bool fallback; };
 
 // growth-order restatement: the seed sits at the anchor end; extension starts at offset S
 // (K-1 walking RIGHT: Seed(0,0,K-1,K-1); K walking LEFT: Seed(len-K, len-K, len-1, len-1)).
@@ -1296,7 +1296,11 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 // MODE 0: the band fits one diagonal per lane (x up to 31: two thirds of all calls, and the instance the hot path's
 // registers and instruction cache see); 1: phases of one, two and four diagonals per lane (up to 255 diagonals);
 // 2: WIDE, with an eight-wide phase behind them (up to 511)
-template <int MODE>
+// LEAF: the instance the path search calls for its own Trails — it makes no call (what would need one, the anti-diagonal
+// sweep or a score by alignment, is reported as `fallback` and the caller asks the general function), so it saves and
+// restores nothing; and it takes the two anchors for equal, which they are by construction there (a Trail starts with
+// the anchor its reference starts with): the general form compares them, one more round trip to memory per scoring.
+template <int MODE, bool LEAF = false>
 TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
                                        bool withScore) {
   PROF_DECL;
@@ -1304,7 +1308,7 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
   const int K = (int)X.P.K;
   const int S = X.dirRight ? K - 1 : K;
   SeedExt r;
-  r.stop = false; r.score = 0;
+  r.stop = false; r.score = 0; r.fallback = false;
   // seq1 (database, H, rows) = the longer (reference unless strictly shorter), seq2 (query, V, cols)
   const bool state = !(refLen < candLen);
   const uint8_t* seq1 = state ? ref : cand; const int len1 = state ? refLen : candLen;
@@ -1354,6 +1358,7 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
       }
     }
     else rc = -1;
+    if (LEAF && rc < 0) { r.fallback = true; return r; }
     if (rc < 0) {   // band wider than the wavefront routines take: the anti-diagonal sweep
       rc = -1;
       const unsigned long long packed = xdrop_sweep(seq2 + S, qlen, seq1 + S, dlen, xdrop);
@@ -1374,8 +1379,9 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
     // x-drop value of the cell it stopped on is exactly that (a defined cell holds the best path from the origin;
     // a path that leaves the x-drop region costs more than x, the cell's own cost is at most x).
     if (withScore) {
-      bool sameAnchor = false;
-      if (rc == 1) {   // (the reference does not require equal anchors; every caller on the correction path has them)
+      bool sameAnchor = LEAF && rc == 1;
+      if (LEAF && !sameAnchor) { r.fallback = true; return r; }
+      if (!LEAF && rc == 1) {   // (the reference does not require equal anchors; every caller on the correction path has them)
         const int l = lane_id();
         sameAnchor = ballot64(l < S && ((gcu8)ref)[l < S ? l : 0] != ((gcu8)cand)[l < S ? l : 0]) == 0ull;
       }
@@ -1394,6 +1400,10 @@ TALC_DNC SeedExt seed_and_extension_wide(const uint8_t* ref, int refLen, const u
 }
 TALC_DN SeedExt seed_and_extension_mid(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
   return seed_and_extension_body<1>(ref, refLen, cand, candLen, xdrop, withScore);
+}
+// the leaf instance for bands of at most 63 diagonals; anything else: fallback
+TALC_DN SeedExt seed_and_extension_leaf(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop) {
+  return seed_and_extension_body<0, true>(ref, refLen, cand, candLen, xdrop, true);
 }
 TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
   {   // more than 255 diagonals (and a stage that takes the segments): the wide instance
@@ -1465,7 +1475,8 @@ TALC_D bool trail_seed_and_extend(int set_, int t_, int len_, int xdrop_) {
   const int set = uni(set_), t = uni(t_), len = uni(len_), xdrop = uni(xdrop_);
   WSYNC();   // the Trail's last bases were appended by lane 0: make them visible to the DP lanes
   const uint32_t buf = (uint32_t)uni((int)tr_buf(set, t));
-  const SeedExt e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)buf * X.C.seqCap, len, xdrop, true);
+  SeedExt e = seed_and_extension_leaf(X.ref, (int)X.refLen, X.seqPool + (uint64_t)buf * X.C.seqCap, len, xdrop);
+  if (uni((int)e.fallback) != 0) e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)buf * X.C.seqCap, len, xdrop, true);
   const int lenHistExt = uni(e.lenHistExt), score = uni(e.score), posOnRef = uni(e.posOnRef);
   const bool stop = uni((int)e.stop) != 0;
   TrailRec r = tr_get(set, t);
