@@ -1401,8 +1401,20 @@ TALC_DNC SeedExt seed_and_extension_wide(const uint8_t* ref, int refLen, const u
 TALC_DN SeedExt seed_and_extension_mid(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
   return seed_and_extension_body<1>(ref, refLen, cand, candLen, xdrop, withScore);
 }
-// the leaf instance for bands of at most 63 diagonals; anything else: fallback
+// the leaf instances: bands of at most 63 diagonals, and (entered by a tail call) of 64 to 255; anything else: fallback
+TALC_DN SeedExt seed_and_extension_mid_leaf(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop) {
+  return seed_and_extension_body<1, true>(ref, refLen, cand, candLen, xdrop, true);
+}
 TALC_DN SeedExt seed_and_extension_leaf(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop) {
+  {
+    const int rl = uni(refLen), cl = uni(candLen), x = max(uni(xdrop), 0);
+    const int S = uni(X.dirRight) ? (int)X.P.K - 1 : (int)X.P.K;
+    const int qlen = min(rl, cl) - S, dlen = max(rl, cl) - S;
+    if (qlen > 0 && dlen > 0) {
+      const int nd = min(x, qlen) + min(x, dlen) + 1;
+      if (nd > 63 && nd <= 255) [[clang::musttail]] return seed_and_extension_mid_leaf(ref, refLen, cand, candLen, xdrop);
+    }
+  }
   return seed_and_extension_body<0, true>(ref, refLen, cand, candLen, xdrop, true);
 }
 TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
