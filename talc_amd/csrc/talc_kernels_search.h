@@ -1066,7 +1066,12 @@ TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
 // side 1: anchorRIGHTHandSide (walks the RIGHT region rightwards from its start, degree towards LEFT)
 TALC_DNC void sort_anchors_long(AnchorRec* anc, int n, double cc) { gnu_sort(anc, n, LessAnchor{cc}); }
 
-TALC_DN void build_anchors(int side) {
+// LEAF: the instance for the common anchor list — a region of at most 64 k-mers whose degrees k_coverage left with the
+// counts, a dozen anchors at most — makes no call at all, so it has nothing to save or restore (2.4 M calls per config-2
+// launch); whatever it cannot settle it reports by returning false BEFORE any flag is raised, and the general instance
+// redoes the list from scratch.
+template <bool LEAF>
+TALC_D bool build_anchors_body(int side) {
   PROF_DECL;
   PROF_BEGIN();
   const DevParams& P = X.P;
@@ -1090,6 +1095,7 @@ TALC_DN void build_anchors(int side) {
   // reads memory position by position.
   const CovRead cr = cur_cov();
   const bool inRegs = nbKmers <= 64u;
+  if (LEAF && !inRegs) return false;
   uint2 regv = make_uint2(0u, 0u), headv = make_uint2(0u, 0u);
   // (a clean region — k_structure — holds the pair of position p at its start's index + (p - start): one load, no word)
   const uint32_t regHidx = (uint32_t)uni((int)(side == 0 ? X.LH : X.RH));
@@ -1116,7 +1122,7 @@ TALC_DN void build_anchors(int side) {
   LSYNC();
   // packed k-mer (+ N mask) of the read's position pos (uniform, inside the region): as wave_kmer_at
   auto kmer_at = [&](uint32_t pos, uint64_t& kmer, uint64_t& nmask) {
-    if (!inRegs) { wave_kmer_at(X.read + pos, (int)K, kmer, nmask); return; }
+    if (!LEAF && !inRegs) { wave_kmer_at(X.read + pos, (int)K, kmer, nmask); return; }
     const uint32_t c = ((uint32_t)l < K) ? (uint32_t)pbase[pos - rs + (uint32_t)l] : 0u;
     nmask = ballot64(((uint32_t)l < K) && (c > 3u));
     uint64_t v = ((uint32_t)l < K) ? ((uint64_t)(c & 3u) << (2 * (K - 1 - (uint32_t)l))) : 0ull;
@@ -1125,9 +1131,9 @@ TALC_DN void build_anchors(int side) {
   };
   auto run_x = [&](uint32_t pos) -> uint32_t { return park[(pos - rs) & 63u]; };
   auto run_y = [&](uint32_t pos) -> uint32_t { return park[64u + ((pos - rs) & 63u)]; };
-#define RUNX(pos) (inRegs ? run_x(pos) : (clean ? (*(const v2u32 TALC_AS1*)(cr.hits + hbase + ((pos) - rs))).x : COVX(pos)))
-#define RUNY(pos) (inRegs ? run_y(pos) : (clean ? (*(const v2u32 TALC_AS1*)(cr.hits + hbase + ((pos) - rs))).y : COVY(pos)))
-#define HEADX(a) (((a) < (uint32_t)kHeadCov) ? (uint32_t)uni((int)park[128u + (a)]) : COVX(a))
+#define RUNX(pos) ((LEAF || inRegs) ? run_x(pos) : (clean ? (*(const v2u32 TALC_AS1*)(cr.hits + hbase + ((pos) - rs))).x : COVX(pos)))
+#define RUNY(pos) ((LEAF || inRegs) ? run_y(pos) : (clean ? (*(const v2u32 TALC_AS1*)(cr.hits + hbase + ((pos) - rs))).y : COVY(pos)))
+#define HEADX(a) (((a) < (uint32_t)kHeadCov) ? (uint32_t)uni((int)park[128u + (a)]) : (LEAF ? 0u : COVX(a)))
   uint32_t current_count = (uint32_t)uni((int)RUNX(pivot));
   uint32_t nPos = 0;
   if (l == 0) anchorPos[0] = pivot;
@@ -1151,7 +1157,7 @@ TALC_DN void build_anchors(int side) {
         const bool fIn = ((ballot64(inRange) >> f) & 1ull) != 0ull;
         if ((current_count >= MINC) & fIn) {
           const uint32_t pf = (uint32_t)lane_get((int)pos, f);
-          if (nPos < cap) { if (l == 0) anchorPos[nPos] = pf; ++nPos; } else X.overflow |= OVF_ANCHORS;
+          if (nPos < cap) { if (l == 0) anchorPos[nPos] = pf; ++nPos; } else { if (LEAF) return false; X.overflow |= OVF_ANCHORS; }
           current_count = (uint32_t)lane_get((int)nc, f);
           from = f + 1;
         } else { alive = false; break; }
@@ -1165,12 +1171,14 @@ TALC_DN void build_anchors(int side) {
   // every k-mer of the table; any other position (count 0: never a recorded one) is probed here
   const int degDir = (side == 0) ? 1 : 0;
   const int degShift = (side == 0) ? kCovDegRShift : kCovDegLShift;
+  bool needGeneral = false;   // (LEAF: a degree k_coverage did not leave)
   auto degree_at = [&](bool want, uint32_t pos) -> int {
     const uint32_t cyAll = RUNY(want ? pos : pivot);
     const uint32_t cy = want ? cyAll : kCovDegKnown;
     int degree = (int)((cy >> degShift) & 7u);
     const bool unknown = want && !(cy & kCovDegKnown);
     if (ballot64(unknown) != 0ull) {
+      if (LEAF) { needGeneral = true; return 0; }
       if (unknown) { uint64_t km, nm; lane_kmer_at(X.read + pos, (int)K, km, nm); degree = dev_out_degree(X.T, MINC, km, nm, degDir); }
     }
     return want ? degree : 0;
@@ -1180,6 +1188,7 @@ TALC_DN void build_anchors(int side) {
     const bool valid = a < nPos;
     const uint32_t pos = valid ? anchorPos[a] : 0u;
     const int degree = degree_at(valid && a != 0, pos);   // (the pivot is taken whatever its degree)
+    if (LEAF && needGeneral) return false;
     unsigned long long take = ballot64(valid && ((a == 0) || (degree > 1)));
     while (take != 0ull) {
       const int f = (int)__builtin_ctzll(take);
@@ -1189,11 +1198,12 @@ TALC_DN void build_anchors(int side) {
         const uint32_t pf = (uint32_t)lane_get((int)pos, f);
         uint64_t km, nm;
         kmer_at(pf, km, nm);
+        if (LEAF && base + (uint32_t)f >= (uint32_t)kHeadCov) return false;
         const uint32_t recorded = HEADX(base + (uint32_t)f);
         if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, recorded};
         if (nAnc == 0) firstAnchorPos = pf;
         ++nAnc;
-      } else X.overflow |= OVF_ANCHORS;
+      } else { if (LEAF) return false; X.overflow |= OVF_ANCHORS; }
     }
   }
   const uint32_t want = min(P.MIN_START_ANCHORS, nbKmers);
@@ -1213,6 +1223,7 @@ TALC_DN void build_anchors(int side) {
         const bool valid = idx < remaining;
         const uint32_t pos = pivot - 1 - (valid ? idx : 0u);
         const int degree = degree_at(valid, pos);
+        if (LEAF && needGeneral) return false;
         unsigned long long branching = ballot64(valid && degree > 1);
         while (branching != 0ull && nAnc < want) {
           const int f = (int)__builtin_ctzll(branching);
@@ -1224,7 +1235,7 @@ TALC_DN void build_anchors(int side) {
             const uint32_t cpf = (uint32_t)uni((int)RUNX(pf));
             if (l == 0) anc[nAnc] = AnchorRec{km, nm, pf, cpf};
             ++nAnc;
-          } else { X.overflow |= OVF_ANCHORS; full = true; break; }
+          } else { if (LEAF) return false; X.overflow |= OVF_ANCHORS; full = true; break; }
         }
       }
     } else {
@@ -1235,11 +1246,15 @@ TALC_DN void build_anchors(int side) {
         if (goFurther) {
           uint64_t km, nm;
           kmer_at(j + 1, km, nm);
-          const int degree = dev_out_degree(X.T, MINC, km, nm, 0);
+          // (its degree towards LEFT is with its count — j + 1 lies in the region, a k-mer of the table —: no probe)
+          const uint32_t cy1 = (uint32_t)uni((int)RUNY(j + 1));
+          int degree;
+          if (cy1 & kCovDegKnown) degree = (int)((cy1 >> kCovDegLShift) & 7u);
+          else { if (LEAF) return false; degree = dev_out_degree(X.T, MINC, km, nm, 0); }
           if (degree > 1) {
             const uint32_t cj1 = (uint32_t)uni((int)RUNX(j + 1));
             if (nAnc < cap) { if (l == 0) anc[nAnc] = AnchorRec{km, nm, j + 1, cj1}; ++nAnc; }
-            else X.overflow |= OVF_ANCHORS;
+            else { if (LEAF) return false; X.overflow |= OVF_ANCHORS; }
           }
         }
       }
@@ -1249,8 +1264,9 @@ TALC_DN void build_anchors(int side) {
   // std::sort of a list of at most 16 elements IS its final insertion sort (the introsort loop does nothing below 17):
   // nearly every anchor list is that short, and the full routine — a real call — keeps its stack arrays and registers
   // out of this function
+  if (LEAF && nAnc > 16) return false;
   if (l == 0 && nAnc > 1) {
-    if (nAnc <= 16) gs_insertion_sort(anc, 0, (int)nAnc, LessAnchor{X.lambda / P.ERR});
+    if (LEAF || nAnc <= 16) gs_insertion_sort(anc, 0, (int)nAnc, LessAnchor{X.lambda / P.ERR});
     else sort_anchors_long(anc, (int)nAnc, X.lambda / P.ERR);
   }
   WSYNC();
@@ -1259,6 +1275,12 @@ TALC_DN void build_anchors(int side) {
 #undef RUNY
 #undef HEADX
   PROF_END(PF_ANCHORS);
+  return true;
+}
+TALC_DN bool build_anchors_leaf(int side) { return build_anchors_body<true>(side); }
+TALC_DN void build_anchors_general(int side) { (void)build_anchors_body<false>(side); }
+TALC_D void build_anchors(int side) {
+  if (!uni((int)build_anchors_leaf(side))) build_anchors_general(side);
 }
 
 // the anti-diagonal form of the x-drop extension (anti-diagonals in LDS, or in HBM when too long): the fallback for a band
