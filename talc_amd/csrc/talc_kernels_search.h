@@ -875,7 +875,7 @@ TALC_DN void edit_and_lcs(const uint8_t* a_, int la, const uint8_t* b_, int lb, 
 // The question a LONE bridge candidate is asked (Explorer.cpp:973: is its identity with the reference at least
 // MIN_INNER): does the LCS of the two sequences reach acceptLcs?  Returns acceptLcs or the exact LCS, as edit_and_lcs
 // with needEdit = false does — through the two narrow wavefront instances only, which settle nearly every gap of a
-// unique-sequence graph; anything else goes to edit_and_lcs.  (A function of its own: edit_and_lcs carries six wavefront
+// unique-sequence graph; anything else returns -1 and the caller asks edit_and_lcs.  (A function of its own: edit_and_lcs carries six wavefront
 // instances and the bit-vector routines, 7000 instructions, and this is the call the bridge search makes per gap.)
 TALC_DN int lcs_reaches(const uint8_t* a_, int la, const uint8_t* b_, int lb, int acceptLcs_) {
   la = uni(la); lb = uni(lb);
@@ -900,9 +900,7 @@ TALC_DN int lcs_reaches(const uint8_t* a_, int la, const uint8_t* b_, int lb, in
     if (d >= 0) return (la + lb - d) >> 1;
     if (d == -2) return acceptLcs;
   }
-  int es = 0, lcs = 0;
-  edit_and_lcs(a, la, b, lb, es, lcs, false, acceptLcs);
-  return uni(lcs);
+  return -1;   // (not settled here: the caller asks edit_and_lcs — this function makes no call and saves nothing)
 }
 
 // ------------------------------------------------------------------ trace helpers
@@ -2475,7 +2473,10 @@ TALC_D void init_first_trail(const AnchorRec& a, const AnchorRec* inList, bool w
   (void)inList;
   pool_reset();
   const uint32_t b0 = (uint32_t)pool_alloc();
-  copy_bytes(X.seqPool + (uint64_t)b0 * X.C.seqCap, X.read + a.pos, (uint32_t)K, !X.dirRight);
+  {   // the anchor's K <= 31 bases in growth order: one base per lane
+    const int l0 = lane_id();
+    if (l0 < K) ((gu8)(X.seqPool + (uint64_t)b0 * X.C.seqCap))[l0] = ((gcu8)X.read)[a.pos + (uint32_t)(X.dirRight ? l0 : K - 1 - l0)];
+  }
   // a bridge search's first buffer starts without a kept alignment row.  Every other buffer a search hands out gets its
   // record from row_copy (branch_copy, garden), so no record is ever read that this search has not written: the stamps in
   // a record's end words (row_covered) are a second line of defence, not the guarantee.
@@ -2653,7 +2654,9 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
         }
         es = 0; lcs = 0;
         if (uni((int)needed)) {
-          if (X.nFull == 1 && accept > 0) lcs = lcs_reaches(X.ref, (int)X.refLen, ps, (int)fm.len, accept);
+          int quick = -1;
+          if (X.nFull == 1 && accept > 0) quick = uni(lcs_reaches(X.ref, (int)X.refLen, ps, (int)fm.len, accept));
+          if (quick >= 0) lcs = quick;
           else edit_and_lcs(X.ref, (int)X.refLen, ps, (int)fm.len, es, lcs, X.nFull > 1, accept);
         }
         score = (double)es;
