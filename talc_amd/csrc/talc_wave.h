@@ -490,11 +490,18 @@ TALC_D unsigned long long lds_load_u64(const uint8_t TALC_AS3* p) {
 // Written without branches inside a slot (the number of equal leading bytes of two 8-byte words is a handful of
 // VALU ops): the first round compares eight bases — on a diagonal off the alignment a run is rarely longer than one or
 // two bases — the later rounds sixteen.
+// v_ffbl_b32 as the hardware has it: the position of the lowest set bit, 0xFFFFFFFF for zero (the compiler's count-
+// trailing-zeros wraps it in a compare and a select per use to define the zero case; here 0xFFFFFFFF is what is wanted)
+TALC_D unsigned ffbl_raw(unsigned x) {
+  unsigned r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 TALC_D unsigned wfa_equal_prefix8(unsigned long long x, unsigned long long y) {   // number of equal leading (low) bytes, 0..8
   const unsigned long long w = x ^ y;
   const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
-  // __ffs(0) = 0: the "- 1" makes an all-equal half 0xFFFFFFFF, which loses every min below
-  const unsigned t = min((unsigned)__ffs((int)lo) - 1u, ((unsigned)__ffs((int)hi) - 1u) | 32u);
+  // an all-equal half gives 0xFFFFFFFF (unchanged by the "| 32"), which loses every min below
+  const unsigned t = min(ffbl_raw(lo), ffbl_raw(hi) | 32u);
   return min(t >> 3, 8u);
 }
 template <int NR>
