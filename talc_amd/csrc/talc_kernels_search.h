@@ -1709,11 +1709,11 @@ TALC_D void make_child(int t, int c, int b, int len, uint32_t count, double dist
 
 // Trail::ThinkIveAlreadyGotThere (Trail.cpp:289-302) for child c (length len+1, tip km2/nm2)
 // against its parent t
-TALC_D bool is_cycle(int t, int c, int len, uint64_t km2, uint64_t nm2) {
+// ... the exact window search behind the filter: a real, cold call (the filter answers "nowhere yet" for 99 % of the
+// generic steps of a unique-sequence graph, and the search's body does not belong in the step's loop)
+TALC_DNC bool is_cycle_exact(int t_, int c_, int len_) {
+  const int t = uni(t_), c = uni(c_), len = uni(len_);
   const int K = (int)X.P.K;
-  const bool maybe = bloom_query_insert(km2, nm2);
-  if (!(len > K)) return false;
-  if (!maybe) return false;   // the k-mer occurs nowhere in this search so far
   WSYNC();
   const uint8_t* parent = trail_seq(X.ia, t);
   const uint8_t* child = trail_seq(X.ia ^ 1, c);
@@ -1727,7 +1727,13 @@ TALC_D bool is_cycle(int t, int c, int len, uint64_t km2, uint64_t nm2) {
   const int q = wave_find_window(parent, len, pat, K, true);
   return q >= 0 && q != len - K;
 }
-
+TALC_D bool is_cycle(int t, int c, int len, uint64_t km2, uint64_t nm2) {
+  const int K = (int)X.P.K;
+  const bool maybe = bloom_query_insert(km2, nm2);
+  if (!(len > K)) return false;
+  if (!maybe) return false;   // the k-mer occurs nowhere in this search so far
+  return uni((int)is_cycle_exact(t, c, len)) != 0;
+}
 TALC_D void swap_sets() { X.ia ^= 1; }
 
 // doABitOfGardening on the new set (n trails); survivors are copied into the other set, which
@@ -1879,7 +1885,8 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
       // the last successor of this Trail inherits its sequence buffer
       const int lastI = last_successor(tags);
       if (lastI < 0) pool_free(tr_buf(X.ia, t));   // no successor: the Trail just ends
-      for (int i = 0; i < 4; ++i) {
+#pragma nounroll
+      for (int i = 0; i < 4; ++i) {   // (one copy of the child's code, not four)
         const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
         if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
         const uint32_t nc = (i == 0) ? pnc0 : (i == 1) ? pnc1 : (i == 2) ? pnc2 : pnc3;
@@ -2029,7 +2036,8 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
                    pdd3 = shfl_f64(mine.dist[3], tt);
       int counter = 0;
       const int lastI = last_successor(tags);
-      for (int i = 0; i < 4; ++i) {
+#pragma nounroll
+      for (int i = 0; i < 4; ++i) {   // (one copy of the child's code, not four)
         const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
         if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
         ++counter;
