@@ -67,7 +67,7 @@ def _fullsize_case(name, n_kmers, n_reads, k, junctions, synth_kw, n_spot, min_c
     tab.upload(0)
     gc, gj = tab.lookup(probe)
     assert (oc == gc).all() and (oj == gj).all()
-    walk = tab.device_bytes > 2.5 * 2 * 32 * (2 * len(tab))      # (two bucket tables at load 0.5 are 128 B per k-mer)
+    walk = tab.device_bytes > 1.5 * 2 * 32 * (2 * len(tab))      # (two bucket tables at load 0.5 are 128 B per k-mer, the walk tables as much again)
     ctx = T.Context(tab, p, 0)
     bases, offs = S.reads(0, n_reads)
     t1 = time.time()
