@@ -59,7 +59,7 @@ def test_coverage_edge_cases(gpu_pair):
     base, offs0 = gpu_pair.reads(0, 6)
     r = PU.seqs_of(base, offs0)
     reads = ["", "ACGT", r[0][:21], r[0][:22], r[1].lower(), r[2][:500] + "N" + r[2][500:], "N" * 100,
-             r[3][:2048 + 20], r[3][:2048 + 21], r[4] + r[5] + r[0] + r[1],     # tile boundaries (COV_TILE = 2048)
+             r[3][:2048 + 20], r[3][:2048 + 21], r[3][:512 + 20], r[3][:512 + 21], r[4] + r[5] + r[0] + r[1],     # tile boundaries (tiles of 512 positions)
              "RYKMSW" + r[5][:100]]
     bases, offs = pack(reads)
     b = gpu_pair.ctx.batch(bases, offs)
@@ -73,6 +73,50 @@ def test_coverage_edge_cases(gpu_pair):
             assert (oc == gc).all() and (oj == j[int(ko[i]):int(ko[i + 1])]).all(), i
             assert onin == nin[i]
     b.close()
+
+
+def _clean_reads(pair, first, n, rate):
+    """Reads of the pair's own transcriptome (same seed and size: the generator's transcripts do not depend on the error
+    rates) with `rate` substitutions / insertions / deletions each instead of 4 %."""
+    from talc_amd.synth import Synth
+    S = Synth(target_kmers=int(pair.synth.spec.target_kmers), k=pair.synth.k, seed=int(pair.synth.spec.seed),
+              sub_rate=rate, ins_rate=rate, del_rate=rate)
+    return S.reads(first, n)
+
+
+def test_coverage_of_dense_reads_and_tile_boundaries(gpu_pair):
+    """The device keeps the coverage as hits + bitmap words per tile of 512 positions: error-free reads (every position a
+    hit, every tile full, ranks up to 511), reads cut at the tile boundaries, and nearly clean reads whose solid regions
+    run across several tiles."""
+    base, offs0 = _clean_reads(gpu_pair, 0, 12, 0.0)
+    r = [s for s in PU.seqs_of(base, offs0) if len(s) > 1100][:4]
+    assert len(r) >= 3
+    reads = [r[0], r[0][:511 + 20], r[0][:512 + 20], r[0][:513 + 20], r[1][:1024 + 20], r[1][:1023 + 21], r[2],
+             r[2][:300] + "N" + r[2][301:], r[1][:700].lower()]
+    b2, o2 = _clean_reads(gpu_pair, 50, 20, 0.003)
+    reads += PU.seqs_of(b2, o2)
+    bases, offs = pack(reads)
+    b = gpu_pair.ctx.batch(bases, offs)
+    b.coverage()
+    c, j, ko, nin = b.fetch_coverage()
+    nfull = 0
+    for i, s in enumerate(reads):
+        oc, oj, onin = gpu_pair.otab.coverage(s)
+        gc = c[int(ko[i]):int(ko[i + 1])]
+        assert (oc == gc).all() and (oj == j[int(ko[i]):int(ko[i + 1])]).all() and onin == nin[i], i
+        nfull += int((gc > 0).all())
+    assert nfull >= 6            # the error-free ones are hits from end to end
+    b.close()
+
+
+def test_correction_of_nearly_clean_reads(gpu_pair):
+    """Solid regions of hundreds of k-mers: the anchor search's regions exceed 64 k-mers (no lane prefetch), cross tile
+    boundaries (no hit index) and get long anchor lists; few and short gaps."""
+    for rate, n in ((0.003, 80), (0.0, 12)):
+        bases, offs = _clean_reads(gpu_pair, 200, n, rate)
+        bad, (so, ost), (sg, gst) = PU.compare_correction(gpu_pair, bases, offs, verbose=False)
+        assert not bad, (rate, bad[:5])
+        assert (ost == 0).sum() >= n - 2
 
 
 def test_coverage_many_reads(gpu_pair):
