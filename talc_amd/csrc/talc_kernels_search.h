@@ -1322,7 +1322,7 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 // the anchor its reference starts with): the general form compares them, one more round trip to memory per scoring.
 template <int MODE, bool LEAF = false>
 TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop,
-                                       bool withScore) {
+                                       bool withScore, uint32_t keepKey = 0) {
   PROF_DECL;
   refLen = uni(refLen); candLen = uni(candLen); xdrop = uni(xdrop); ref = uni_ptr(ref); cand = uni_ptr(cand);
   const int K = (int)X.P.K;
@@ -1362,12 +1362,12 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
         }
       }
     }
-    else if (MODE == 0 && ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells);
+    else if (MODE == 0 && ndiagonals <= 63) rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, nullptr, state ? keepKey : 0u);
     else if (MODE == 1 && ndiagonals <= 255) {   // (the hand-over state lives in the HBM DP arrays: make_caps keeps them at 2048 ints or more)
       // in phases (WfaPhase): levels 0..31 one diagonal per lane, 32..63 two, the rest four
       int* mem = X.dpG + 2ull * X.C.dpCap + 256;   // (past the flags of the multi-x run)
       WfaPhase ph{-1, 31, mem, mem + 512};
-      rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+      rc = wave_xdrop_wfa<1>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph, state ? keepKey : 0u);
       if (rc == 2) {
         ph.fromLevel = 31; ph.toLevel = (ndiagonals <= 127) ? -1 : 63;
         rc = wave_xdrop_wfa<2>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
@@ -1422,20 +1422,20 @@ TALC_DN SeedExt seed_and_extension_mid(const uint8_t* ref, int refLen, const uin
   return seed_and_extension_body<1>(ref, refLen, cand, candLen, xdrop, withScore);
 }
 // the leaf instances: bands of at most 63 diagonals, and (entered by a tail call) of 64 to 255; anything else: fallback
-TALC_DN SeedExt seed_and_extension_mid_leaf(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop) {
-  return seed_and_extension_body<1, true>(ref, refLen, cand, candLen, xdrop, true);
+TALC_DN SeedExt seed_and_extension_mid_leaf(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, uint32_t keepKey) {
+  return seed_and_extension_body<1, true>(ref, refLen, cand, candLen, xdrop, true, keepKey);
 }
-TALC_DN SeedExt seed_and_extension_leaf(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop) {
+TALC_DN SeedExt seed_and_extension_leaf(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, uint32_t keepKey) {
   {
     const int rl = uni(refLen), cl = uni(candLen), x = max(uni(xdrop), 0);
     const int S = uni(X.dirRight) ? (int)X.P.K - 1 : (int)X.P.K;
     const int qlen = min(rl, cl) - S, dlen = max(rl, cl) - S;
     if (qlen > 0 && dlen > 0) {
       const int nd = min(x, qlen) + min(x, dlen) + 1;
-      if (nd > 63 && nd <= 255) [[clang::musttail]] return seed_and_extension_mid_leaf(ref, refLen, cand, candLen, xdrop);
+      if (nd > 63 && nd <= 255) [[clang::musttail]] return seed_and_extension_mid_leaf(ref, refLen, cand, candLen, xdrop, keepKey);
     }
   }
-  return seed_and_extension_body<0, true>(ref, refLen, cand, candLen, xdrop, true);
+  return seed_and_extension_body<0, true>(ref, refLen, cand, candLen, xdrop, true, keepKey);
 }
 TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t* cand, int candLen, int xdrop, bool withScore) {
   {   // more than 255 diagonals (and a stage that takes the segments): the wide instance
@@ -1507,7 +1507,8 @@ TALC_D bool trail_seed_and_extend(int set_, int t_, int len_, int xdrop_) {
   const int set = uni(set_), t = uni(t_), len = uni(len_), xdrop = uni(xdrop_);
   WSYNC();   // the Trail's last bases were appended by lane 0: make them visible to the DP lanes
   const uint32_t buf = (uint32_t)uni((int)tr_buf(set, t));
-  SeedExt e = seed_and_extension_leaf(X.ref, (int)X.refLen, X.seqPool + (uint64_t)buf * X.C.seqCap, len, xdrop);
+  // (the kept wavefront, talc_wave.h: the pair is this search's reference and the Trail in buffer `buf`)
+  SeedExt e = seed_and_extension_leaf(X.ref, (int)X.refLen, X.seqPool + (uint64_t)buf * X.C.seqCap, len, xdrop, buf + 1u);
   if (uni((int)e.fallback) != 0) e = seed_and_extension(X.ref, (int)X.refLen, X.seqPool + (uint64_t)buf * X.C.seqCap, len, xdrop, true);
   const int lenHistExt = uni(e.lenHistExt), score = uni(e.score), posOnRef = uni(e.posOnRef);
   const bool stop = uni((int)e.stop) != 0;
@@ -1679,6 +1680,7 @@ TALC_DNC uint32_t branch_copy(uint32_t parentBuf_, int len_, bool bridge_) {
   const uint32_t parentBuf = (uint32_t)uni((int)parentBuf_);
   const int len = uni(len_);
   const uint32_t cbuf = (uint32_t)pool_alloc();
+  if (lane_id() == 0) g_keep.owner = 0u;   // (a buffer changes hands: a kept wavefront may be about its former contents)
   WSYNC();   // bases appended by lane 0 in earlier steps must be visible to the copying lanes
   wave_copy(X.seqPool + (uint64_t)cbuf * X.C.seqCap, X.seqPool + (uint64_t)parentBuf * X.C.seqCap, (uint32_t)len);
   if (uni((int)bridge_) != 0) row_copy(cbuf, parentBuf);
@@ -1743,6 +1745,7 @@ TALC_DNC int garden(int n, int len, bool& isComplex) {
   __shared__ int s_cx;
   const int l = lane_id();
   const int ib = X.ia ^ 1;   // the Trails to rank
+  if (l == 0) g_keep.owner = 0u;   // (the survivors move to fresh buffers)
   WSYNC();
   for (int i = l; i < n; i += 64) { const TrailRec r = tr_get(ib, i); X.gScores[i] = (double)r.score; X.gDists[i] = r.dist; }
   WSYNC();
@@ -2500,6 +2503,7 @@ TALC_D void init_first_trail(const AnchorRec& a, const AnchorRec* inList, bool w
     WSYNC();
   }
   X.wideMask = (uint32_t)uni((int)wm);
+  if (lane_id() == 0) g_keep.owner = 0u;   // (no wavefront of an earlier search is this one's)
   g_bloom[lane_id()] = 0ull; g_bloom[lane_id() + 64] = 0ull;
   LSYNC();
   if (withAims) {

@@ -640,10 +640,22 @@ __shared__ uint32_t g_wprof[4];   // staging, levels, selection of wave_xdrop_wf
 #define WPROF_ADD(i, t0) ((void)(t0))
 #endif
 
+// A kept wavefront.  An edge search scores its one live Trail every CHECK_INTERVAL steps: the same database segment
+// (the read's edge), the query (the Trail) a few bases longer, x a little larger each time.  Level e of the recurrence
+// depends on the two segments only up to the furthest points it reaches, on x only through the diagonals |k| = x, and
+// on the query's length only once a diagonal has followed the query to its end: the last level of a run BEFORE any
+// diagonal touched the query's end (and below the run's x) is level e of every later run of the same pair with a longer
+// query and a larger x.  The first phase (one diagonal per lane) keeps that level here, by diagonal, and the next run
+// of the same pair — `keepKey` names the pair; whoever changes a Trail buffer's contents resets `owner` — starts from
+// it.  A third of an extension's levels on average (the true cost of the Trail against the edge, ~ an eighth of its
+// length, against an x of a third of it), all of them from the narrow phase.
+struct WfaKeep { uint32_t owner; int level; int qlenAt; int pad_; int F[64]; int E[64]; };
+__shared__ WfaKeep g_keep;
+
 template <int NR>
 TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const uint8_t* __restrict__ dbSeg_, int dlen, int x,
                           uint8_t TALC_AS3* stage, int stageCap, int& extCols, int& extRows, int& extScore,
-                          unsigned long long& cells, const WfaPhase* ph = nullptr) {
+                          unsigned long long& cells, const WfaPhase* ph = nullptr, uint32_t keepKey_ = 0) {
   gcu8 querySeg = (gcu8)uni_ptr(querySeg_); gcu8 dbSeg = (gcu8)uni_ptr(dbSeg_);
   const int l = lane_id();
   qlen = uni(qlen); dlen = uni(dlen); x = uni(x);
@@ -683,6 +695,31 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   bool cornerHit = false;
   int cornerE = 0;
   int eStart = 1;
+  // keep / resume (NR == 1, first phase only)
+  const uint32_t keepKey = (NR == 1 && fromLevel < 0) ? (uint32_t)uni((int)keepKey_) : 0u;
+  bool tracking = keepKey != 0u;
+  const int kOfLane = kmin + l;
+  const int aq = 2 * qlen - kOfLane;           // the anti-diagonal on which this lane's diagonal meets the query's end
+  bool resumed = false;
+  if (NR == 1 && keepKey != 0u) {
+    const int lv = uni(g_keep.level), qat = uni(g_keep.qlenAt);
+    if ((uint32_t)uni((int)g_keep.owner) == keepKey && lv >= 1 && lv < x && lv <= 31 && lv < qat && qat <= qlen && lv < dlen) {
+      const int ak = kOfLane < 0 ? -kOfLane : kOfLane;
+      const bool in = (l < nd) & (ak <= lv);
+      F[0] = in ? g_keep.F[(kOfLane + 32) & 63] : NEG;
+      E[0] = in ? g_keep.E[(kOfLane + 32) & 63] : 0;
+      eStart = lv + 1;
+      resumed = true;
+    }
+  }
+  auto keep_level = [&](int level) {   // the current F / E are level `level`'s
+    if (level >= 1 && level <= 31) {
+      if (l < nd) { g_keep.F[(kOfLane + 32) & 63] = F[0]; g_keep.E[(kOfLane + 32) & 63] = E[0]; }
+      if (l == 0) { g_keep.owner = keepKey; g_keep.level = level; g_keep.qlenAt = qlen; }
+    }
+  };
+  if (resumed) {
+  } else
   if (fromLevel >= 0) {   // the state the narrower phase left behind
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
@@ -704,6 +741,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 #pragma unroll
     for (int s = 0; s < NR; ++s) hit |= ballot64(F[s] == corner);
     cornerHit = hit != 0ull;
+    if (tracking && ballot64(F[0] == aq) != 0ull) tracking = false;   // level 0 runs to the query's end: nothing to keep
   }
   const int eEnd = (toLevel >= 0) ? min(x, toLevel) : x;
   unsigned long long work = 0;
@@ -713,6 +751,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   const bool cornerInBand = (kc >= kmin) & (kc <= kmax);
   int eLast = eStart - 1;
   for (int e = eStart; e <= eEnd && !cornerHit; ++e) {
+    if (NR == 1 && tracking && e == x) { keep_level(e - 1); tracking = false; }   // level x is the one x itself shapes (forb)
     int rotR[NR], rotL[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) { rotR[s] = lane_ror1(F[s]); rotL[s] = lane_rol1(F[s]); }
@@ -737,6 +776,10 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 #pragma unroll
     for (int s = 0; s < NR; ++s) moved[s] = act[s];
     extend(b, act);
+    if (NR == 1 && tracking && ballot64(moved[0] && b[0] == aq) != 0ull) {   // this level meets the query's end: keep the one before
+      keep_level(e - 1);
+      tracking = false;
+    }
     unsigned long long hit = 0;
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
@@ -746,6 +789,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     if (hit != 0ull) { cornerHit = true; cornerE = e; }
     eLast = e;
   }
+  if (NR == 1 && tracking && !cornerHit && eLast < x) keep_level(eLast);   // (a phase that ends below x untouched)
   if (eLast >= eStart) {   // the levels' diagonals, counted once: sum over e = eStart..eLast of min(nd, 2 e + 1)
     const int eh = min(eLast, (nd - 1) / 2);   // levels whose 2 e + 1 diagonals all fit the band
     const int lo = max(eh, eStart - 1);
