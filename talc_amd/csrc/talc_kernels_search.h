@@ -3205,6 +3205,29 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
       ++calls;
     }
     if (lane_id() == 0) { out[0] = calls; out[1] = nbad; out[2] = first; out[5] = (int)X.overflow; }
+  } else if (mode == 8) {
+    // mode 8: the kept wavefront (talc_wave.h: WfaKeep).  a = the reference, b = the candidate; the candidate's first
+    // m = p0, p0 + p2, ... <= lb bases are scored as an edge search scores its Trail — x starts at p3 and follows the
+    // scores (x = -score + 2, Explorer.cpp:713) — once through the leaf instances with a key (level kept / resumed from
+    // call to call) and once through the general function (from level 0): out[0] = scorings, out[1] = those that
+    // differ, out[2] = the first such m, out[3] = scorings that did resume
+    int calls = 0, nbad = 0, first = -1, nres = 0;
+    int x = p3;
+    if (lane_id() == 0) g_keep.owner = 0u;
+    WSYNC();
+    for (int m = p0; m <= lb; m += max(p2, 1)) {
+      const int lvBefore = ((uint32_t)uni((int)g_keep.owner) == 1u) ? uni(g_keep.level) : 0;
+      SeedExt e1 = seed_and_extension_leaf(a, la, b, m, x, 1u);
+      if (uni((int)e1.fallback) != 0) e1 = seed_and_extension(a, la, b, m, x, true);
+      else if (lvBefore >= 1 && lvBefore < x) ++nres;
+      const SeedExt e0 = seed_and_extension(a, la, b, m, x, true);
+      const bool bad = (uni(e0.lenRefExt) != uni(e1.lenRefExt)) || (uni(e0.lenHistExt) != uni(e1.lenHistExt)) || (uni(e0.posOnRef) != uni(e1.posOnRef)) ||
+                       (uni(e0.score) != uni(e1.score)) || (uni((int)e0.stop) != uni((int)e1.stop));
+      if (bad) { if (first < 0) first = m; ++nbad; }
+      ++calls;
+      x = max(-uni(e0.score), 0) + 2;
+    }
+    if (lane_id() == 0) { out[0] = calls; out[1] = nbad; out[2] = first; out[3] = nres; out[5] = (int)X.overflow; }
   } else if (mode == 4) {
     // mode 4: edit_and_lcs(a, b) -> out[0] = global (0,-1,-1) score, out[1] = LCS length
     int es = 0, lcs = 0;

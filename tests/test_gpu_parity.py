@@ -338,6 +338,47 @@ def test_device_multi_xdrop_run_equals_the_single_runs(gpu_pair):
     assert used > 250
 
 
+def test_device_kept_wavefront_equals_the_extension_from_scratch(gpu_pair):
+    """An edge search scores its growing Trail every few steps; the seed extension keeps the last wavefront level that
+    had not met the Trail's end and the next scoring resumes from it (talc_wave.h: WfaKeep).  Every scoring of a growing
+    candidate through that path must equal the extension from level 0 — for candidates that follow the reference with
+    ONT-like errors, that diverge from it, that are identical to it, and for both directions."""
+    rnd = random.Random(17)
+    K = 21
+    total = resumed = 0
+    for it in range(60):
+        n = rnd.randint(120, 700)
+        ref = "".join(rnd.choice("ACGT") for _ in range(n))
+        kind = it % 4
+        cand = list(ref)
+        if kind == 0:      # noisy copy (12 % errors), same anchor
+            out = []
+            for ch in ref[K:]:
+                u = rnd.random()
+                if u < 0.04:
+                    continue
+                if u < 0.08:
+                    out.append(rnd.choice("ACGT"))
+                out.append(ch if u >= 0.12 else rnd.choice("ACGT"))
+            cand = ref[:K] + "".join(out)
+        elif kind == 1:    # follows for a while, then random
+            cut = rnd.randint(K + 5, n // 2)
+            cand = ref[:cut] + "".join(rnd.choice("ACGT") for _ in range(n - cut))
+        elif kind == 2:    # identical
+            cand = ref
+        else:              # few errors
+            cand = "".join(ch if rnd.random() > 0.02 else rnd.choice("ACGT") for ch in ref)
+            cand = ref[:K] + cand[K:]
+        cand = cand[: min(len(cand), 600)]
+        step = rnd.choice([1, 3, 6, 6, 6, 11])
+        for dir_right in (1, 0):
+            out = gpu_pair.ctx.test_dp(8, ref, cand, K + step, dir_right, step, rnd.choice([2, 3, 3, 5]))
+            assert out[1] == 0, (it, kind, dir_right, step, out[:4])
+            total += out[0]
+            resumed += out[3]
+    assert total > 2000 and resumed > total // 4, (total, resumed)
+
+
 def test_device_window_search(gpu_pair):
     rnd = random.Random(5)
     ctx = gpu_pair.ctx
