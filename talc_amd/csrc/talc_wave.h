@@ -649,7 +649,9 @@ __shared__ uint32_t g_wprof[4];   // staging, levels, selection of wave_xdrop_wf
 // of the same pair — `keepKey` names the pair; whoever changes a Trail buffer's contents resets `owner` — starts from
 // it.  A third of an extension's levels on average (the true cost of the Trail against the edge, ~ an eighth of its
 // length, against an x of a third of it), all of them from the narrow phase.
-struct WfaKeep { uint32_t owner; int level; int qlenAt; int pad_; int F[64]; int E[64]; };
+// (F as 16 bits — an anti-diagonal of segments the LDS stage holds — with 0xFFFF for "not reached", E as 8: LDS is handed
+//  out to the one-wave workgroups of k_search in steps of 1280 bytes and the kernel sits just below one)
+struct WfaKeep { uint32_t owner; int level; int qlenAt; int pad_; uint16_t F[64]; uint8_t E[64]; };
 __shared__ WfaKeep g_keep;
 
 template <int NR>
@@ -706,15 +708,16 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
     if ((uint32_t)uni((int)g_keep.owner) == keepKey && lv >= 1 && lv < x && lv <= 31 && lv < qat && qat <= qlen && lv < dlen) {
       const int ak = kOfLane < 0 ? -kOfLane : kOfLane;
       const bool in = (l < nd) & (ak <= lv);
-      F[0] = in ? g_keep.F[(kOfLane + 32) & 63] : NEG;
-      E[0] = in ? g_keep.E[(kOfLane + 32) & 63] : 0;
+      const uint32_t f16 = g_keep.F[(kOfLane + 32) & 63];
+      F[0] = (in && f16 != 0xFFFFu) ? (int)f16 : NEG;
+      E[0] = in ? (int)g_keep.E[(kOfLane + 32) & 63] : 0;
       eStart = lv + 1;
       resumed = true;
     }
   }
   auto keep_level = [&](int level) {   // the current F / E are level `level`'s
     if (level >= 1 && level <= 31) {
-      if (l < nd) { g_keep.F[(kOfLane + 32) & 63] = F[0]; g_keep.E[(kOfLane + 32) & 63] = E[0]; }
+      if (l < nd) { g_keep.F[(kOfLane + 32) & 63] = (uint16_t)(F[0] >= 0 ? F[0] : 0xFFFF); g_keep.E[(kOfLane + 32) & 63] = (uint8_t)E[0]; }
       if (l == 0) { g_keep.owner = keepKey; g_keep.level = level; g_keep.qlenAt = qlen; }
     }
   };
