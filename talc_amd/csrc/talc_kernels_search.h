@@ -577,11 +577,13 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     // of the launch, waiting for a few late heavy reads).
     // (in wave-cycles, from the category profile of config 2: a step of the walk ~ 460, a wavefront level ~ 1500,
     //  a level per ~ 11 bases of path at 12 % error: an inner gap of g bases ~ 870 g + 20 000, an edge of h bases
-    //  ~ 5 anchors x (550 h + 27 h^2))
+    //  ~ 5 anchors x (550 h + 27 h^2); the 14 g^2 of a gap is fitted: replaying the per-read times of one launch through
+    //  the queue, the last reads to finish were those with one 400-600 base gap, whose evaluation is quadratic as well —
+    //  with the term the replayed launch is 4.6 % shorter on config 2 and 19 % shorter on the branching workload)
     unsigned long long part = 0;
     for (uint32_t i = l; i + 1 < Rfinal; i += 64) {
       const unsigned long long g = (regS[i + 1] > regE[i] + K) ? (unsigned long long)(regS[i + 1] - (regE[i] + K)) : 0ull;
-      part += 870ull * g + 20000ull;
+      part += 870ull * g + 14ull * g * g + 20000ull;
     }
     unsigned long long cost = wave_sum_u64(part);
     const unsigned long long head = regS[0], eLast = regE[Rfinal - 1];

@@ -1190,13 +1190,26 @@ TALC_D int wave_find_window(const uint8_t* __restrict__ seq_, int len, const uin
   // K >= 18: the first 8 bytes filter all but ~4^-8 of the windows with one unaligned 8-byte load
   const uint64_t p8 = load_u64_unaligned(pat);
   const int nchunk = (nwin + 63) >> 6;
-  for (int c = 0; c < nchunk; ++c) {
-    const int base = wantLast ? (nchunk - 1 - c) * 64 : c * 64;
-    const int q = base + l;
-    bool eq = (q < nwin) && (load_u64_unaligned(seq + q) == p8);
-    if (eq) for (int i = 8; i < K; ++i) if (seq[q + i] != pat[i]) { eq = false; break; }
-    const unsigned long long m = ballot64(eq);
-    if (m) return wantLast ? base + 63 - (int)__clzll((long long)m) : base + (int)__ffsll((long long)m) - 1;
+  // four chunks' loads are issued before the first is looked at: the chunks of one search are independent, and a search
+  // that stops at the first hit would otherwise wait for one load after the other (a branching graph asks this question
+  // for every child whose k-mer any Trail of the search has seen: a fifth of such a launch)
+  for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    int base[4]; uint64_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j;
+      base[j] = wantLast ? (nchunk - 1 - c) * 64 : c * 64;
+      const int q = base[j] + l;
+      w[j] = (c < nchunk && q < nwin) ? load_u64_unaligned(seq + q) : ~p8;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = base[j] + l;
+      bool eq = (w[j] == p8);
+      if (eq) for (int i = 8; i < K; ++i) if (seq[q + i] != pat[i]) { eq = false; break; }
+      const unsigned long long m = ballot64(eq);
+      if (m) return wantLast ? base[j] + 63 - (int)__clzll((long long)m) : base[j] + (int)__ffsll((long long)m) - 1;
+    }
   }
   return -1;
 }
