@@ -1061,6 +1061,33 @@ TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
   return maybe;
 }
 
+// The generic step asks first and enters afterwards: the k-mers of a step's children go into the filter together when
+// the step is over (bloom_flush; lane i holds the upper hash half of the step's i-th child), so that a child is not
+// answered "maybe" because a sibling or a cousin reached the same k-mer in this very step — a k-mer of its own path was
+// entered at an earlier step, by one of its ancestors.  (Two Trails that went round the two sides of a substitution
+// bubble walk on in step, k-mer for k-mer, until gardening drops one: with the entries made at once each of their steps
+// paid for an exact window search — a fifth of a launch over a branching graph.)
+TALC_D bool bloom_query(uint64_t kmer, uint64_t nmask, uint32_t& hv) {
+  const uint64_t h = bloom_hash(kmer, nmask);
+  hv = (uint32_t)(h >> 32);
+  const uint32_t wm = (uint32_t)uni((int)X.wideMask);
+  if (wm != 0u) {
+    const unsigned long long m = wide_bits(hv);
+    return (wide_load(X.wideBloom + wide_word(hv, wm)) & m) == m;
+  }
+  const unsigned long long m = bloom_mask(h);
+  return (g_bloom[bloom_word(h)] & m) == m;
+}
+TALC_D void bloom_flush(uint32_t pend, int n) {
+  if (n == 0) return;
+  const uint32_t wm = (uint32_t)uni((int)X.wideMask);
+  if (lane_id() < n) {
+    if (wm != 0u) wide_or(X.wideBloom + wide_word(pend, wm), wide_bits(pend));
+    else atomicOr(&g_bloom[pend >> 25], (1ull << ((pend >> 19) & 63u)) | (1ull << ((pend >> 13) & 63u)));
+  }
+  LSYNC();
+}
+
 // ------------------------------------------------------------------ anchors (Explorer.cpp:413-543)
 // side 0: anchorLEFTHandSide (walks the LEFT region leftwards from its end, degree towards RIGHT)
 // side 1: anchorRIGHTHandSide (walks the RIGHT region rightwards from its start, degree towards LEFT)
@@ -1731,9 +1758,9 @@ TALC_DNC bool is_cycle_exact(int t_, int c_, int len_) {
   const int q = wave_find_window(parent, len, pat, K, true);
   return q >= 0 && q != len - K;
 }
-TALC_D bool is_cycle(int t, int c, int len, uint64_t km2, uint64_t nm2) {
+TALC_D bool is_cycle(int t, int c, int len, uint64_t km2, uint64_t nm2, uint32_t& hv) {
   const int K = (int)X.P.K;
-  const bool maybe = bloom_query_insert(km2, nm2);
+  const bool maybe = bloom_query(km2, nm2, hv);
   if (!(len > K)) return false;
   if (!maybe) return false;   // the k-mer occurs nowhere in this search so far
   return uni((int)is_cycle_exact(t, c, len)) != 0;
@@ -1871,6 +1898,7 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   const int nAims = X.dirRight ? X.nAncR : X.nAncL;
   const int ib = X.ia ^ 1;
   int nNew = 0;
+  uint32_t pend = 0; int nPend = 0;   // this step's children, to be entered into the filter (bloom_flush)
   const bool complexIn = ((uint32_t)nCur > P.MAXB);
   for (int base = 0; base < nCur; base += 64) {
     const int tl = base + l;
@@ -1923,14 +1951,18 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
           ++nNew;
         } else {
           PROF_BEGIN();
-          const bool cyc = uni((int)is_cycle(t, nNew, len, km2, nm2)) != 0;
+          uint32_t hv;
+          const bool cyc = uni((int)is_cycle(t, nNew, len, km2, nm2, hv)) != 0;
           PROF_END(PF_CYCLE);
           if (cyc) { pool_free(tr_buf(ib, nNew)); continue; }   // :586-587 pop_back
+          if (l == nPend) pend = hv;
+          if (++nPend == 64) { bloom_flush(pend, 64); nPend = 0; }
           ++nNew;
         }
       }
     }
   }
+  bloom_flush(pend, nPend);
   const bool complex = ((uint32_t)nNew > P.MAXB);
   ++stepCounter;
   int nOut;
@@ -2023,6 +2055,7 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
   const int l = lane_id();
   const int ib = X.ia ^ 1;
   int nNew = 0;
+  uint32_t pend = 0; int nPend = 0;   // (see bloom_query)
   const bool complexIn = (nCur > 7);   // :634 hard-coded
   for (int base = 0; base < nCur; base += 64) {
     const int tl = base + l;
@@ -2055,7 +2088,8 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
         make_child<false>(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
         PROF_END(PF_CHILD);
         PROF_BEGIN();
-        const bool cycle = uni((int)is_cycle(t, nNew, len, km2, nm2)) != 0;
+        uint32_t hv;
+        const bool cycle = uni((int)is_cycle(t, nNew, len, km2, nm2, hv)) != 0;
         PROF_END(PF_CYCLE);
         if (cycle || (stepCounter + 1 > PATH_MAXLENGTH)) {
           trail_seed_and_extend(ib, nNew, len + 1, xdrop);
@@ -2063,6 +2097,8 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
           pool_free(tr_buf(ib, nNew));
           continue;   // pop_back
         }
+        if (l == nPend) pend = hv;
+        if (++nPend == 64) { bloom_flush(pend, 64); nPend = 0; }
         ++nNew;
       }
       if (counter == 0) {   // dead end (:657-662)
@@ -2072,6 +2108,7 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
       }
     }
   }
+  bloom_flush(pend, nPend);
   ++stepCounter;
   int nOut;
   if ((stepCounter % P.CHECK_INTERVAL == 0) || ((uint32_t)nNew >= P.MAX_BORDER_PATHS)) {
