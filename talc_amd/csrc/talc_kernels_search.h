@@ -657,11 +657,12 @@ struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online 
 enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
        PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
        PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX,
-       PF_XSTAGE, PF_XLEV, PF_XSEL, PF_REFB, PF_RESULT, PF_N };
+       PF_XSTAGE, PF_XLEV, PF_XSEL, PF_REFB, PF_RESULT, PF_CYQ, PF_CYX, PF_CYHIT, PF_CYFILL, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
                        "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
                        "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords", "#reads<0.25ms", "#reads<1ms", "#reads<4ms", \
-                       "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)", "x.stage", "x.levels", "x.select", "b.ref", "b.result"}
+                       "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)", "x.stage", "x.levels", "x.select", "b.ref", "b.result", \
+                       "#cyc.query", "#cyc.exact", "#cyc.found", "cyc.fill%sum"}
 
 struct Wv {
   // kernel constants
@@ -1761,9 +1762,21 @@ TALC_DNC bool is_cycle_exact(int t_, int c_, int len_) {
 TALC_D bool is_cycle(int t, int c, int len, uint64_t km2, uint64_t nm2, uint32_t& hv) {
   const int K = (int)X.P.K;
   const bool maybe = bloom_query(km2, nm2, hv);
+#ifdef TALC_PROF
+  if (lane_id() == 0) { g_prof[PF_CYQ] += 1; if (maybe && len > K) g_prof[PF_CYX] += 1; }
+  if (maybe && len > K && X.wideMask == 0u) {   // how full the LDS filter is when it says "maybe" (percent, summed)
+    int pc = __popcll(g_bloom[lane_id()]) + __popcll(g_bloom[lane_id() + 64]);
+    for (int o = 32; o > 0; o >>= 1) pc += __shfl_xor(pc, o);
+    if (lane_id() == 0) g_prof[PF_CYFILL] += (uint32_t)(pc * 100 / 8192);
+  }
+#endif
   if (!(len > K)) return false;
   if (!maybe) return false;   // the k-mer occurs nowhere in this search so far
-  return uni((int)is_cycle_exact(t, c, len)) != 0;
+  const bool found = uni((int)is_cycle_exact(t, c, len)) != 0;
+#ifdef TALC_PROF
+  if (lane_id() == 0 && found) g_prof[PF_CYHIT] += 1;
+#endif
+  return found;
 }
 TALC_D void swap_sets() { X.ia ^= 1; }
 
