@@ -986,14 +986,15 @@ TALC_D void row_set_covered(uint32_t buf, uint32_t covered) {
     rec[X.refLen + 1u] = (int)X.launchStamp;
   }
 }
-// the record of the Trail in buffer `src` goes with a copy of that Trail into buffer `dst`
+// the record of the Trail in buffer `src` goes with a copy of that Trail into buffer `dst`: the row AND its stamps, so the
+// copy covers exactly what the original covers (nothing, if the original's stamps are not this search's).  The caller has
+// synchronised since the record was last written (branch_copy, garden: both do before they copy the Trail's bases), and
+// the copy neither waits for that copy's stores nor looks at the stamps first: each was a memory round trip per child.
 TALC_DNC void row_copy(uint32_t dst_, uint32_t src_) {
   const uint32_t dst = (uint32_t)uni((int)dst_), src = (uint32_t)uni((int)src_);
   const uint32_t avail = (uint32_t)uni((int)X.rowAvail);
   if (dst >= avail) return;
-  WSYNC();   // (the record and its stamp were left by other lanes)
-  const uint32_t covered = (src < avail) ? row_covered(src) : 0u;
-  if (covered) wave_copy((uint8_t*)row_of(dst), (const uint8_t*)row_of(src), (uint32_t)uni((int)X.rowStride) * 4u);
+  if (src < avail) wave_copy((uint8_t*)row_of(dst), (const uint8_t*)row_of(src), (uint32_t)uni((int)X.rowStride) * 4u);
   else row_set_covered(dst, 0u);
 }
 // slots >= HOT live in HBM; these are real calls so that the optimiser never merges an LDS and an
@@ -1821,56 +1822,77 @@ TALC_D int last_successor(int tags) {
   return lastI;
 }
 
-// Explorer::oneMoreStep (Explorer.cpp:546-612).  nCur trails of length len in the current set.
-// Trail::Overlapscore (Trail.cpp:145-173) of the Trail in buffer `buf` (m bases) against the first tlen bases of the
-// reference, from the row the Trail (or the Trail it was copied from) left at its last scoring
-TALC_DNC int score_bridge_rows(uint32_t buf_, int tlen_, int m_) {
-  const uint32_t buf = (uint32_t)uni((int)buf_);
-  const int tlen = uni(tlen_), m = uni(m_);
+// scoreBridges (Explorer.cpp:689-706): Trail::Overlapscore (Trail.cpp:145-173) of every Trail of the new set against the
+// reference truncated to K+step+WINDOW (growth-order prefix), each from the row the Trail (or the Trail it was copied
+// from) left at its last scoring.  One instance per width of the reference (NB columns per lane); functions of their own:
+// they only run in complex regions, and the step's common path should not carry their registers.
+// What a scoring waits for is memory, not arithmetic (six new rows are ~ 500 instructions): the reference's bases are
+// fetched once for all Trails, the Trails' buffers and the rows their records cover are looked up one Trail per lane
+// (one round trip for 64 Trails), no Trail waits for the stores of the one before, and only the score goes back into the
+// Trail's record.
+template <int NB>
+TALC_DNC void score_bridges_rows(int ib_, int nNew_, int m_, int tlen_, uint32_t rowAvail_) {
+  const int ib = uni(ib_), nNew = uni(nNew_), m = uni(m_), tlen = uni(tlen_);
+  const uint32_t rowAvail = (uint32_t)uni((int)rowAvail_);
   const int n = (int)uni((int)X.refLen);
-  WSYNC();   // the row and its stamp may have arrived by a copy, the Trail's last bases by lane 0
-  int i0 = (int)row_covered(buf);
-  if (i0 > m) i0 = 0;   // (cannot happen: a Trail only grows)
-  int* row = row_of(buf);
-  const uint8_t* cand = X.seqPool + (uint64_t)buf * X.C.seqCap;
+  const int l = lane_id();
+  unsigned hp[(NB + 3) / 4];
+  nw_rows_cols<NB>(X.ref, n, hp);
+  const uint32_t TALC_AS1* bufG = (const uint32_t TALC_AS1*)uni_ptr(X.G[ib].buf);
+  int TALC_AS1* scoreG = (int TALC_AS1*)uni_ptr(X.G[ib].score);
+  const uint32_t stamp = (uint32_t)uni((int)X.launchStamp), sno = (uint32_t)uni((int)X.searchNo);
   unsigned long long ncells = 0;
-  const int B = (n + 63) >> 6;
-  int sc;
-  if (B <= 2) sc = wave_nw_rows<2>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
-  else if (B <= 4) sc = wave_nw_rows<4>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
-  else if (B <= 6) sc = wave_nw_rows<6>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
-  else if (B <= 8) sc = wave_nw_rows<8>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
-  else if (B <= 12) sc = wave_nw_rows<12>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
-  else if (B <= 16) sc = wave_nw_rows<16>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
-  else if (B <= 24) sc = wave_nw_rows<24>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
-  else sc = wave_nw_rows<32>(X.ref, n, cand, i0, m, 4, -3, -2, row, tlen, ncells);
-  static_assert(ROW_MAX_REF <= 64 * 32 - 1, "the widest instance takes 32 columns per lane");
+  for (int base = 0; base < nNew; base += 64) {
+    const int tj = base + l;
+    uint32_t myBuf = 0xFFFFFFFFu, myCov = 0u;
+    if (tj < nNew) {
+      if (tj < HOT) myBuf = g_hot[ib * HOT + tj].buf;
+      else myBuf = bufG[tj];
+      if (myBuf < rowAvail) {   // row_covered, one Trail per lane
+        const int TALC_AS1* rec = (const int TALC_AS1*)row_of(myBuf);
+        const uint32_t lo = (uint32_t)rec[0], hi = (uint32_t)rec[n + 1];
+        myCov = (hi == stamp && (lo >> 12) == sno) ? (lo & 0xFFFu) : 0u;
+      }
+    }
+    const int cnt = min(64, nNew - base);
+    for (int jj = 0; jj < cnt; ++jj) {
+      const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)myBuf, jj);
+      const uint8_t* cand = X.seqPool + (uint64_t)rb * X.C.seqCap;
+      int sc;
+      if (rb < rowAvail) {
+        int i0 = __builtin_amdgcn_readlane((int)myCov, jj);
+        if (i0 > m) i0 = 0;   // (cannot happen: a Trail only grows)
+        sc = nw_rows_run<NB>(hp, n, cand, i0, m, 4, -3, -2, row_of(rb), tlen, ncells);
+        row_set_covered(rb, (uint32_t)m);
+      } else {
+        sc = nw_score(X.ref, tlen, cand, m, 4, -3, -2, true);
+      }
+      const int j = base + jj;
+      if (l == 0) { if (j < HOT) g_hot[ib * HOT + j].score = sc; else scoreG[j] = sc; }
+    }
+  }
   X.cells += ncells;
-  row_set_covered(buf, (uint32_t)m);
-  return sc;
+  WSYNC();
 }
+static_assert(ROW_MAX_REF <= 64 * 32 - 1, "the widest instance takes 32 columns per lane");
 
-// scoreBridges (Explorer.cpp:689-706): reference truncated to K+step+WINDOW (growth-order prefix).  (A function of its
-// own: it only runs in complex regions, and the step's common path should not carry its registers.)
 TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_) {
   const DevParams& P = X.P;
   const int ib = uni(ib_), nNew = uni(nNew_), len = uni(len_);
   const uint32_t stepCounter = (uint32_t)uni((int)stepCounter_);
-  const int l = lane_id();
-  {
-    const uint32_t bound = P.K + stepCounter + P.WINDOW;
-    const int tlen = (int)min(bound, X.refLen);
-    WSYNC();
-    const uint32_t rowAvail = ((uint32_t)(len + 1) < 4096u) ? (uint32_t)uni((int)X.rowAvail) : 0u;
-    for (int j = 0; j < nNew; ++j) {
-      TrailRec r = tr_get(ib, j);
-      const uint32_t rb = (uint32_t)uni((int)r.buf);
-      if (rb < rowAvail) r.score = score_bridge_rows(rb, tlen, len + 1);
-      else r.score = nw_score(X.ref, tlen, X.seqPool + (uint64_t)rb * X.C.seqCap, len + 1, 4, -3, -2, true);
-      if (l == 0) tr_put(ib, j, r);
-    }
-    WSYNC();
-  }
+  const uint32_t bound = P.K + stepCounter + P.WINDOW;
+  const int tlen = (int)min(bound, X.refLen);
+  WSYNC();   // rows and stamps may have arrived by a copy, the Trails' last bases by lane 0
+  const uint32_t rowAvail = ((uint32_t)(len + 1) < 4096u) ? (uint32_t)uni((int)X.rowAvail) : 0u;
+  const int B = ((int)uni((int)X.refLen) + 63) >> 6;
+  if (rowAvail == 0u || B <= 2) score_bridges_rows<2>(ib, nNew, len + 1, tlen, rowAvail);   // (no rows: every Trail from scratch, nw_score)
+  else if (B <= 4) score_bridges_rows<4>(ib, nNew, len + 1, tlen, rowAvail);
+  else if (B <= 6) score_bridges_rows<6>(ib, nNew, len + 1, tlen, rowAvail);
+  else if (B <= 8) score_bridges_rows<8>(ib, nNew, len + 1, tlen, rowAvail);
+  else if (B <= 12) score_bridges_rows<12>(ib, nNew, len + 1, tlen, rowAvail);
+  else if (B <= 16) score_bridges_rows<16>(ib, nNew, len + 1, tlen, rowAvail);
+  else if (B <= 24) score_bridges_rows<24>(ib, nNew, len + 1, tlen, rowAvail);
+  else score_bridges_rows<32>(ib, nNew, len + 1, tlen, rowAvail);
 }
 
 // A child of the generic step whose tip is an aim (checkAims, Trail.cpp:273-285): recordBridge (Explorer.cpp:1097-1101).

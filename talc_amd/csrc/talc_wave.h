@@ -333,62 +333,77 @@ TALC_D int wave_nw_reg(const uint8_t* __restrict__ H_, int n, const uint8_t* __r
 // bases nor the truncation of the reference change it — so a Trail that keeps the last row it has computed (over the
 // WHOLE reference) only needs the rows of its new bases: rows i0+1 .. m of the free-begin matrix of V (rows) against H
 // (columns), continued from row i0 in rowIO[1..n] (i0 == 0: row 0 is all zero and rowIO is not read); leaves row m
-// there and returns D[m][outCol] = the score of V[0, m) against H[0, outCol).  Same sweep as wave_nw_reg.
+// there and returns D[m][outCol] = the score of V[0, m) against H[0, outCol).
+// ROW BY ROW, every lane on the same row (the lane-skewed sweep of wave_nw_reg needs rows + lanes - 1 steps, and a scoring
+// adds CHECK_INTERVAL rows: 64 steps for 6 rows).  The one dependency along a row, v[j] = max(a[j], v[j-1] + gap) with
+// a[j] = max(diagonal move, vertical move), is a prefix maximum after the substitution v'[j] = v[j] - j gap
+// (v'[j] = max(a'[j], v'[j-1]), v'[0] = 0: column 0 is free): each lane takes the running maximum of its own columns,
+// one DPP scan gives every lane the maximum of the lanes before it, and a second pass over the own columns finishes the
+// row.  Same integers as the sweep, cell for cell.  The Trail's bases of 64 rows sit in one register (lane k: row k's).
+// (two halves: the lane's column bases depend on the reference alone and serve every Trail of a scoring)
 template <int NB>
-TALC_D int wave_nw_rows(const uint8_t* __restrict__ H_, int n, const uint8_t* __restrict__ V_, int i0, int m, int match, int mismatch,
-                        int gap, int* rowIO_, int outCol, unsigned long long& cells) {
-  gcu8 H = (gcu8)uni_ptr(H_); gcu8 V = (gcu8)uni_ptr(V_);
+TALC_D void nw_rows_cols(const uint8_t* __restrict__ H_, int n, unsigned (&hp)[(NB + 3) / 4]) {
+  gcu8 H = (gcu8)uni_ptr(H_);
+  const int l = lane_id();
+  n = uni(n);
+  const int B = (n + 63) >> 6;
+  const int j0 = l * B + 1;
+  const int nOwn = max(0, min(B, n - j0 + 1));
+#pragma unroll
+  for (int q = 0; q < (NB + 3) / 4; ++q) hp[q] = 0xFFFFFFFFu;
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj)
+    if (jj < nOwn) hp[jj >> 2] = (hp[jj >> 2] & ~(0xFFu << (8 * (jj & 3)))) | ((unsigned)H[j0 + jj - 1] << (8 * (jj & 3)));
+}
+template <int NB>
+TALC_D int nw_rows_run(const unsigned (&hp)[(NB + 3) / 4], int n, const uint8_t* __restrict__ V_, int i0, int m, int match, int mismatch,
+                       int gap, int* rowIO_, int outCol, unsigned long long& cells) {
+  gcu8 V = (gcu8)uni_ptr(V_);
   int TALC_AS1* rowIO = (int TALC_AS1*)uni_ptr(rowIO_);   // [0] belongs to the caller (column 0 is zero by definition)
   const int l = lane_id();
   n = uni(n); m = uni(m); i0 = uni(i0); outCol = uni(outCol); match = uni(match); mismatch = uni(mismatch); gap = uni(gap);
   const int rows = m - i0;
   cells += (unsigned long long)n * (unsigned long long)max(rows, 0);
   const int B = (n + 63) >> 6;
-  const int nl = (n + B - 1) / B;
   const int j0 = l * B + 1;
   const int nOwn = max(0, min(B, n - j0 + 1));
-  constexpr int NP = (NB + 3) / 4;
-  unsigned hp[NP];   // the lane's column bases, four per register
   int r[NB];
 #pragma unroll
-  for (int q = 0; q < NP; ++q) hp[q] = 0xFFFFFFFFu;
+  for (int jj = 0; jj < NB; ++jj) r[jj] = (jj < nOwn && i0 > 0) ? rowIO[j0 + jj] : 0;
+  const int jg0 = j0 * gap;   // j gap of the first own column
+  int vreg = (l < rows) ? (int)V[i0 + l] : 0;
+  for (int c0 = 0; c0 < rows; c0 += 64) {
+    const int vnext = (c0 + 64 + l < rows) ? (int)V[i0 + c0 + 64 + l] : 0;   // (asked for 64 rows ahead)
+    const int cr = min(64, rows - c0);
+    for (int i = 0; i < cr; ++i) {
+      const int vb = __builtin_amdgcn_readlane(vreg, i);
+      int lastOwn = 0;   // the row above at the last own column
 #pragma unroll
-  for (int jj = 0; jj < NB; ++jj) {
-    const int j = j0 + jj;
-    if (jj < nOwn) hp[jj >> 2] = (hp[jj >> 2] & ~(0xFFu << (8 * (jj & 3)))) | ((unsigned)H[j - 1] << (8 * (jj & 3)));
-    r[jj] = (jj < nOwn && i0 > 0) ? rowIO[j] : 0;
-  }
-  int lastOut = 0;   // row i0 at the last own column
-#pragma unroll
-  for (int jj = 0; jj < NB; ++jj) if (jj == nOwn - 1) lastOut = r[jj];
-  int prevLastOut = lastOut;
-  const int T = rows + nl - 1;
-  int vcur = (l == 0 && rows > 0) ? (int)V[i0] : 0;
-  for (int t = 1; t <= T; ++t) {
-    int vnext = 0;
-    { const int idx = t - l; if (idx >= 0 && idx < rows) vnext = (int)V[i0 + idx]; }
-    const int nbLast = lane_shr1(lastOut);
-    const int nbPrev = lane_shr1(prevLastOut);
-    const int i = t - l;
-    if (l < nl && i >= 1 && i <= rows) {
-      int left = (l == 0) ? 0 : nbLast, diag = (l == 0) ? 0 : nbPrev;   // (column 0 is free: all zero)
-      int v = left;
+      for (int jj = 0; jj < NB; ++jj) if (jj == nOwn - 1) lastOwn = r[jj];
+      int diag = lane_shr1(lastOwn);
+      diag = (l == 0) ? 0 : diag;   // (column 0 is free: all zero)
+      int pm = INT_MIN / 2;
+      int ap[NB];
 #pragma unroll
       for (int jj = 0; jj < NB; ++jj) {
+        ap[jj] = INT_MIN / 2;
         if (jj < nOwn) {
           const int up = r[jj];
           const int hb = (int)((hp[jj >> 2] >> (8 * (jj & 3))) & 0xFFu);
-          const int d = diag + ((hb == vcur) ? match : mismatch);
-          v = max(d, max(up + gap, left + gap));
-          r[jj] = v;
+          const int a = max(diag + ((hb == vb) ? match : mismatch), up + gap);
           diag = up;
-          left = v;
+          pm = max(pm, a - (jg0 + jj * gap));
+          ap[jj] = pm;
         }
       }
-      prevLastOut = diag;
-      lastOut = v;
+      int sc = pm;   // (INT_MIN / 2 in a lane without columns)
+      TALC_WAVE_REDUCE(sc, max, INT_MIN);   // inclusive prefix maximum over the lanes
+      int e = lane_shr1(sc);
+      e = (l == 0) ? 0 : max(e, 0);
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) if (jj < nOwn) r[jj] = max(ap[jj], e) + (jg0 + jj * gap);
     }
-    vcur = vnext;
+    vreg = vnext;
   }
 #pragma unroll
   for (int jj = 0; jj < NB; ++jj) if (jj < nOwn) rowIO[j0 + jj] = r[jj];
@@ -397,6 +412,13 @@ TALC_D int wave_nw_rows(const uint8_t* __restrict__ H_, int n, const uint8_t* __
 #pragma unroll
   for (int jj = 0; jj < NB; ++jj) if (jj == tj) res = r[jj];
   return lane_get(res, ln);
+}
+template <int NB>
+TALC_D int wave_nw_rows(const uint8_t* __restrict__ H_, int n, const uint8_t* __restrict__ V_, int i0, int m, int match, int mismatch,
+                        int gap, int* rowIO_, int outCol, unsigned long long& cells) {
+  unsigned hp[(NB + 3) / 4];   // the lane's column bases, four per register
+  nw_rows_cols<NB>(H_, n, hp);
+  return nw_rows_run<NB>(hp, n, V_, i0, m, match, mismatch, gap, rowIO_, outCol, cells);
 }
 
 // ------------------------------------------------------------------ fused edit distance + LCS (n <= 64*NB)

@@ -235,7 +235,8 @@ def test_device_edit_distance_and_lcs_beyond_4096_columns(gpu_pair):
 def test_device_alignment_rows_continued_equal_the_alignment_from_scratch(gpu_pair):
     """scoreBridges (Explorer.cpp:689-706): the device keeps every Trail's last alignment row over the whole reference and
     adds the rows of the Trail's new bases (wave_nw_rows).  References of 30 to 2047 bases (every instance, 2 to 32
-    columns per lane), candidates growing by 1..9 bases, truncation windows of 5-15: the kept row's entry against the
+    columns per lane), candidates growing by 1..17 bases from a first scoring of 21 or 70-200 bases, truncation windows of
+    5-15: the kept row's entry against the
     alignment from scratch (nw_score, itself pinned to the oracle above) at every scoring."""
     rnd = random.Random(97)
     ctx = gpu_pair.ctx
@@ -254,11 +255,14 @@ def test_device_alignment_rows_continued_equal_the_alignment_from_scratch(gpu_pa
                 cand.append(ch)
         cand = cand + [rnd.choice("ACGT") for _ in range(15)]
         step = rnd.choice([1, 3, 6, 6, 9]) if n <= 260 else rnd.choice([6, 9, 17])
-        got = ctx.test_dp(7, "".join(ref), "".join(cand), 21, 0, step, rnd.choice([5, 10, 15]))
-        assert got[5] == 0 and got[0] > 0
-        assert got[1] == 0, (n, len(cand), step, "first differing length", int(got[2]))
-        total += int(got[0])
-    assert total > 400
+        for first in (21, rnd.choice([70, 130, 200])):   # rows of the first scoring: within one 64-row block / over several
+            if first > len(cand):
+                continue
+            got = ctx.test_dp(7, "".join(ref), "".join(cand), first, 0, step, rnd.choice([5, 10, 15]))
+            assert got[5] == 0 and got[0] > 0
+            assert got[1] == 0, (n, len(cand), first, step, "first differing length", int(got[2]))
+            total += int(got[0])
+    assert total > 700
 
 
 def test_device_seed_and_extension_matches_oracle(gpu_pair):
