@@ -53,6 +53,36 @@ class Pair:
         return self.synth.reads(first, n)
 
 
+class CustomPair:
+    """Oracle table + product table from explicit transcripts (forward-strand k-mers, `depth` per occurrence): for graph
+    shapes the synthetic generator does not make (tandem repeats -> cycles)."""
+
+    def __init__(self, transcripts, k=21, depth=20, **params_kw):
+        self.p, self.q = both_params(k=k, **params_kw)
+        code = {"A": 0, "C": 1, "G": 2, "T": 3}
+        cnt = {}
+        mask = (1 << (2 * k)) - 1
+        for t in transcripts:
+            v = 0
+            for i, ch in enumerate(t):
+                v = ((v << 2) | code[ch]) & mask
+                if i >= k - 1:
+                    cnt[v] = cnt.get(v, 0) + depth
+        self.keys = np.fromiter(cnt.keys(), dtype=np.uint64, count=len(cnt))
+        self.counts = np.fromiter(cnt.values(), dtype=np.uint32, count=len(cnt))
+        self.otab = O.OracleTable(self.q, O.OracleTable.FLAT)
+        self.otab.insert_packed(self.keys, self.counts)
+        self.ttab = T.Table.from_arrays(self.keys, self.counts, self.p)
+        self.otab.decolour()
+        self.ttab.decolour_repeats()
+        self.ctx = None
+
+    def upload(self, device=0):
+        self.ttab.upload(device)
+        self.ctx = T.Context(self.ttab, self.p, device)
+        return self.ctx
+
+
 def seqs_of(buf, offs):
     b = bytes(buf)
     return [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(len(offs) - 1)]

@@ -563,6 +563,60 @@ def test_retry_stage_that_does_not_fit_is_a_warning_not_an_error(gpu_pair, monke
     ctx2.close()
 
 
+def _noisy(rnd, seq, rate):
+    out = []
+    for ch in seq:
+        x = rnd.random()
+        if x < rate * 0.4:
+            out.append(rnd.choice("ACGT"))          # substitution
+        elif x < rate * 0.7:
+            continue                                # deletion
+        elif x < rate:
+            out.append(ch)
+            out.append(rnd.choice("ACGT"))          # insertion
+        else:
+            out.append(ch)
+    return "".join(out)
+
+
+def test_correction_across_tandem_repeats_and_cycles():
+    """Tandem repeats with a unit longer than K put cycles into the graph: a Trail that walks into the second copy of the
+    unit meets a k-mer of its own path, Trail::ThinkIveAlreadyGotThere (Trail.cpp:289-302) says so and oneMoreStep /
+    oneMoreStepInTheDark drop it (Explorer.cpp:586, 648-655).  The synthetic transcriptomes of the other cases never take
+    that branch (0 of 24 M window searches of the branching bench workload find anything).  Units of K+2 .. 3K bases, 2-6
+    copies, a diverged copy in some (a bubble next to the cycle), reads with 8-14 % errors across them."""
+    rnd = random.Random(1234)
+    k = 21
+    transcripts = []
+    for t in range(60):
+        parts = ["".join(rnd.choice("ACGT") for _ in range(rnd.randint(150, 400)))]
+        for _ in range(rnd.randint(1, 3)):
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(k + 2, 3 * k)))
+            copies = rnd.randint(2, 6)
+            for c in range(copies):
+                u = unit
+                if rnd.random() < 0.3:   # a copy with one substitution
+                    i = rnd.randrange(len(u))
+                    u = u[:i] + rnd.choice("ACGT".replace(u[i], "")) + u[i + 1:]
+                parts.append(u)
+            parts.append("".join(rnd.choice("ACGT") for _ in range(rnd.randint(100, 350))))
+        transcripts.append("".join(parts))
+    pair = PU.CustomPair(transcripts, k=k, depth=20)
+    pair.upload(0)
+    reads = []
+    for t in transcripts:
+        for _ in range(4):
+            a = rnd.randint(0, 60)
+            b = len(t) - rnd.randint(0, 60)
+            reads.append(_noisy(rnd, t[a:b], rnd.choice([0.08, 0.11, 0.14])))
+    bases, offs = pack(reads)
+    bad, (so, ost), (sg, gst) = PU.compare_correction(pair, bases, offs, nthreads=8, verbose=False)
+    if bad:
+        d = PU.first_trace_diff(pair, bases, offs, bad[0])
+        raise AssertionError("reads %s differ (of %d); first trace difference of read %d: %s" % (bad[:8], len(reads), bad[0], d))
+    assert (ost == 0).sum() > 200
+
+
 def test_one_context_over_batches_of_changing_shape_on_a_branching_graph():
     """The kept alignment rows of scoreBridges live in a per-wave arena that is never reset: batches of different
     longest reads (the scratch slots move) and searches of different reference lengths (the records' stride changes)
