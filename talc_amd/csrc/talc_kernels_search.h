@@ -1045,24 +1045,26 @@ TALC_D unsigned long long wide_load(const unsigned long long* p) {
 TALC_D void wide_or(unsigned long long* p, unsigned long long m) {
   __hip_atomic_fetch_or(p, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (a search with the wide filter keeps the LDS one as well and asks it first: the wide one costs a memory round trip per
+//  question, and the LDS one — however full a long walk leaves it — still answers most of them; both are supersets of
+//  what was entered, so "absent" from either is exact)
 TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
   const uint64_t h = bloom_hash(kmer, nmask);
   const uint32_t wm = (uint32_t)uni((int)X.wideMask);
-  if (wm != 0u) {
-    const uint32_t hv = (uint32_t)(h >> 32);
-    unsigned long long* w = X.wideBloom + wide_word(hv, wm);
-    const unsigned long long m = wide_bits(hv), v = wide_load(w);
-    if (lane_id() == 0) wide_or(w, m);
-    return (v & m) == m;
-  }
   const int w = bloom_word(h);
   const unsigned long long m = bloom_mask(h), v = g_bloom[w];
-  const bool maybe = (v & m) == m;
+  bool maybe = (v & m) == m;
   if (lane_id() == 0) g_bloom[w] = v | m;
+  if (wm != 0u) {
+    const uint32_t hv = (uint32_t)(h >> 32);
+    unsigned long long* ww = X.wideBloom + wide_word(hv, wm);
+    const unsigned long long mw = wide_bits(hv);
+    if (maybe) maybe = (wide_load(ww) & mw) == mw;
+    if (lane_id() == 0) wide_or(ww, mw);
+  }
   LSYNC();
   return maybe;
 }
-
 // The generic step asks first and enters afterwards: the k-mers of a step's children go into the filter together when
 // the step is over (bloom_flush; lane i holds the upper hash half of the step's i-th child), so that a child is not
 // answered "maybe" because a sibling or a cousin reached the same k-mer in this very step — a k-mer of its own path was
@@ -1072,20 +1074,21 @@ TALC_D bool bloom_query_insert(uint64_t kmer, uint64_t nmask) {
 TALC_D bool bloom_query(uint64_t kmer, uint64_t nmask, uint32_t& hv) {
   const uint64_t h = bloom_hash(kmer, nmask);
   hv = (uint32_t)(h >> 32);
+  const unsigned long long m = bloom_mask(h);
+  if ((g_bloom[bloom_word(h)] & m) != m) return false;
   const uint32_t wm = (uint32_t)uni((int)X.wideMask);
   if (wm != 0u) {
-    const unsigned long long m = wide_bits(hv);
-    return (wide_load(X.wideBloom + wide_word(hv, wm)) & m) == m;
+    const unsigned long long mw = wide_bits(hv);
+    return (wide_load(X.wideBloom + wide_word(hv, wm)) & mw) == mw;
   }
-  const unsigned long long m = bloom_mask(h);
-  return (g_bloom[bloom_word(h)] & m) == m;
+  return true;
 }
 TALC_D void bloom_flush(uint32_t pend, int n) {
   if (n == 0) return;
   const uint32_t wm = (uint32_t)uni((int)X.wideMask);
   if (lane_id() < n) {
+    atomicOr(&g_bloom[pend >> 25], (1ull << ((pend >> 19) & 63u)) | (1ull << ((pend >> 13) & 63u)));
     if (wm != 0u) wide_or(X.wideBloom + wide_word(pend, wm), wide_bits(pend));
-    else atomicOr(&g_bloom[pend >> 25], (1ull << ((pend >> 19) & 63u)) | (1ull << ((pend >> 13) & 63u)));
   }
   LSYNC();
 }
@@ -2447,12 +2450,15 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     static_assert(TALC_WALK_LEVELS == 12, "the lane roles above are written for 12 levels (+ 2 key lanes) in a 16-lane row");
     // aim / cycle query against the search's filter (init_first_trail entered the aims)
     const int bwi = (int)(hv >> 25);     // bloom_word / bloom_mask on the upper half of the hash
-    unsigned long long bm = (1ull << ((hv >> 19) & 63u)) | (1ull << ((hv >> 13) & 63u));
-    unsigned long long bv;
+    const unsigned long long bm = (1ull << ((hv >> 19) & 63u)) | (1ull << ((hv >> 13) & 63u));
+    bool seen = (g_bloom[bwi] & bm) == bm;
     unsigned long long* const wideW = WIDEF ? wideBloom + wide_word(hv, wideMask) : nullptr;
-    if (WIDEF) { bm = wide_bits(hv); bv = (l < TALC_WALK_LEVELS) ? wide_load(wideW) : 0ull; }   // a long search's filter (HBM)
-    else bv = g_bloom[bwi];
-    const unsigned long long hitMask = ballot64(((bv & bm) == bm) || dup) | (1ull << TALC_WALK_LEVELS);
+    const unsigned long long bmW = WIDEF ? wide_bits(hv) : 0ull;
+    if (WIDEF) {   // a long search's filter (HBM): only the levels the LDS filter cannot clear ask it
+      const bool ask = seen && (l < TALC_WALK_LEVELS);
+      if (ballot64(ask) != 0ull) { const unsigned long long bvW = ask ? wide_load(wideW) : 0ull; seen = ask && ((bvW & bmW) == bmW); }
+    }
+    const unsigned long long hitMask = ballot64(seen || dup) | (1ull << TALC_WALK_LEVELS);
     const int hitLevel = __builtin_ctzll(hitMask);
     // a filter hit on a level that could otherwise be taken: if its k-mer is an aim, that step is a plain step that
     // also records the bridge (oneMoreStep, Explorer.cpp:566-583) — taken here as well; anything else (a possible
@@ -2468,7 +2474,8 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     if (nTake == 0) break;
     // ---- commit nTake steps
     if (l < nTake) {
-      if (WIDEF) wide_or(wideW, bm); else atomicOr(&g_bloom[bwi], bm);
+      atomicOr(&g_bloom[bwi], bm);
+      if (WIDEF) wide_or(wideW, bmW);
       recN[done - flushed + l] = top;
       seq[len0 + done + l] = (uint8_t)which;
     }
@@ -2589,7 +2596,7 @@ TALC_D void init_first_trail(const AnchorRec& a, const AnchorRec* inList, bool w
       if (tn != 0ull) continue;   // a fast-forwarded tip never holds an N
       const uint64_t h = bloom_hash(tk, 0ull);
       if (wm != 0u) wide_or(X.wideBloom + wide_word((uint32_t)(h >> 32), wm), wide_bits((uint32_t)(h >> 32)));
-      else atomicOr(&g_bloom[bloom_word(h)], bloom_mask(h));
+      atomicOr(&g_bloom[bloom_word(h)], bloom_mask(h));
     }
     LSYNC();
   }
