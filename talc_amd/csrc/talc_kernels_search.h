@@ -577,15 +577,22 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     // of the launch, waiting for a few late heavy reads).
     // (in wave-cycles, from the category profile of config 2: a step of the walk ~ 460, a wavefront level ~ 1500,
     //  a level per ~ 11 bases of path at 12 % error: an inner gap of g bases ~ 870 g + 20 000, an edge of h bases
-    //  ~ 5 anchors x (550 h + 27 h^2); the 14 g^2 of a gap is fitted: replaying the per-read times of one launch through
-    //  the queue, the last reads to finish were those with one 400-600 base gap, whose evaluation is quadratic as well —
-    //  with the term the replayed launch is 4.6 % shorter on config 2 and 19 % shorter on the branching workload)
-    unsigned long long part = 0;
+    //  ~ 5 anchors x (550 h + 27 h^2)).
+    // ... plus 14 x min(sum of g^2, 900^2): not a cost but a RISK.  Per base a long gap is no dearer than a short one
+    // (0.9 ms per kb of gap for 150-base and for 900-base gaps alike), but one read in a hundred with a 400-600 base gap
+    // takes five times that — and replaying the per-read times of a launch through the queue, those were the reads that
+    // finished last, started late because they looked like 1.5 ms reads.  The term starts every read with a long gap
+    // early; it is bounded because beyond one 900-base gap it says nothing new (on config 5, K = 31, nearly every read
+    // has one, and the unbounded sum put single-gap reads before the truly heavy many-gap ones: 88.8 -> 103 ms).
+    // Replayed launches against the order by true duration, configs 2 / 5 / branching: +3.6-4 % / +2.3 % / +0 %
+    // (without the term +11 % / +2.5 % / +20-24 %; unbounded +3.6-4 % / +15 % / +0 %)
+    unsigned long long part = 0, sq = 0;
     for (uint32_t i = l; i + 1 < Rfinal; i += 64) {
       const unsigned long long g = (regS[i + 1] > regE[i] + K) ? (unsigned long long)(regS[i + 1] - (regE[i] + K)) : 0ull;
-      part += 870ull * g + 14ull * g * g + 20000ull;
+      part += 870ull * g + 20000ull;
+      sq += g * g;
     }
-    unsigned long long cost = wave_sum_u64(part);
+    unsigned long long cost = wave_sum_u64(part) + 14ull * min(wave_sum_u64(sq), 900ull * 900ull);
     const unsigned long long head = regS[0], eLast = regE[Rfinal - 1];
     const unsigned long long tail = (eLast + 1 < n) ? (unsigned long long)L - (eLast + K) : 0ull;
     if (head > 0 && head <= P.MAX_BORDER_LEN) cost += (unsigned long long)P.costEdgeLin * head + (unsigned long long)P.costEdgeQuad * head * head;
@@ -596,10 +603,10 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
       unsigned long long gs = 0;
       for (uint32_t i = l; i + 1 < Rfinal; i += 64) gs += (regS[i + 1] > regE[i] + K) ? (unsigned long long)(regS[i + 1] - (regE[i] + K)) : 0ull;
       st.pfGapSum = (uint32_t)wave_sum_u64(gs);
-      unsigned long long g2 = 0, sr = 0; uint32_t gm = 0;
+      unsigned long long g2 = 0, sr = 0; uint32_t gm = 0;   // (sr: sum of min(g, 640)^2, a candidate term of the estimate)
       for (uint32_t i = l; i < Rfinal; i += 64) {
         const unsigned long long g = (i + 1 < Rfinal && regS[i + 1] > regE[i] + K) ? (unsigned long long)(regS[i + 1] - (regE[i] + K)) : 0ull;
-        g2 += g * g; gm = max(gm, (uint32_t)g); sr += (regE[i] - regS[i] < 2u) ? 1u : 0u;
+        g2 += g * g; gm = max(gm, (uint32_t)g); sr += min(g, 640ull) * min(g, 640ull);
       }
       st.pfGapSq = (uint32_t)min(wave_sum_u64(g2), 0xFFFFFFFFull); st.pfGapMax = wave_max_u32(gm); st.pfShortReg = (uint32_t)wave_sum_u64(sr); st.pfSteps = 0;
       st.pfHead = (uint32_t)head; st.pfTail = (uint32_t)tail; st.pfFork = (uint32_t)nFork; st.pfSolid = (uint32_t)m; st.pfTicks = 0;
