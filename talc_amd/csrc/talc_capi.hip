@@ -650,6 +650,10 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   d.costEdgeLin = 2800; d.costEdgeQuad = 135;
   if (const char* e = getenv("TALC_COST_LIN")) d.costEdgeLin = (uint32_t)strtoul(e, nullptr, 10);     // (tuning runs)
   if (const char* e = getenv("TALC_COST_QUAD")) d.costEdgeQuad = (uint32_t)strtoul(e, nullptr, 10);
+  d.costGapQuad = 10; d.costGapFork = 200; d.costGapCap = 900; d.pad_ = 0;   // (profiles/r03/cost_sweep.txt)
+  if (const char* e = getenv("TALC_COST_GAPQ")) d.costGapQuad = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char* e = getenv("TALC_COST_GAPFORK")) d.costGapFork = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char* e = getenv("TALC_COST_GAPCAP")) d.costGapCap = (uint32_t)strtoul(e, nullptr, 10);
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));

@@ -248,6 +248,8 @@ struct DevParams {
   uint32_t MAX_BORDER_LEN;
   // work estimate of an edge of h bases, in wave-cycles (only the order of the work queue depends on it; k_structure)
   uint32_t costEdgeLin, costEdgeQuad;
+  // ... and the long-gap risk term: (costGapQuad + costGapFork x share of forking solid k-mers) x min(sum g^2, costGapCap^2)
+  uint32_t costGapQuad, costGapFork, costGapCap, pad_;
 };
 
 }  // namespace talc

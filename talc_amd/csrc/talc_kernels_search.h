@@ -400,21 +400,13 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   // STRUCT_HBINS (used when vmax turns out to be below it, which it nearly always is)
   for (int b = l; b < STRUCT_HBINS; b += 64) s_hist[b] = 0;
   WSYNC();
-#ifdef TALC_PROF
-  unsigned long long nFork = 0;   // solid k-mers with more than one successor or predecessor in the graph (per-read rows)
-#endif
+  unsigned long long nFork = 0;   // solid k-mers with more than one successor or predecessor in the graph (the cost estimate)
   cov_for_hits(cov, n, [&](uint32_t x, uint32_t y) {
     if (x >= MINC) { m += 1; vmax = max(vmax, x); if (x < (uint32_t)STRUCT_HBINS) atomicAdd(&s_hist[x], 1u); }
-#ifdef TALC_PROF
     nFork += ((x >= MINC) && (y & kCovDegKnown) && ((((y >> kCovDegRShift) & 7u) > 1u) || (((y >> kCovDegLShift) & 7u) > 1u))) ? 1u : 0u;
-#else
-    (void)y;
-#endif
   });
   m = wave_sum_u64(m);
-#ifdef TALC_PROF
   nFork = wave_sum_u64(nFork);
-#endif
   vmax = wave_max_u32(vmax);
   uint32_t first = 0, last = (uint32_t)m;
   if (m > 10) { first = (uint32_t)(0.15 * (double)m); last = (uint32_t)(0.90 * (double)m); }
@@ -578,21 +570,23 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     // (in wave-cycles, from the category profile of config 2: a step of the walk ~ 460, a wavefront level ~ 1500,
     //  a level per ~ 11 bases of path at 12 % error: an inner gap of g bases ~ 870 g + 20 000, an edge of h bases
     //  ~ 5 anchors x (550 h + 27 h^2)).
-    // ... plus 14 x min(sum of g^2, 900^2): not a cost but a RISK.  Per base a long gap is no dearer than a short one
+    // ... plus q x min(sum of g^2, 900^2): not a cost but a RISK.  Per base a long gap is no dearer than a short one
     // (0.9 ms per kb of gap for 150-base and for 900-base gaps alike), but one read in a hundred with a 400-600 base gap
     // takes five times that — and replaying the per-read times of a launch through the queue, those were the reads that
     // finished last, started late because they looked like 1.5 ms reads.  The term starts every read with a long gap
     // early; it is bounded because beyond one 900-base gap it says nothing new (on config 5, K = 31, nearly every read
-    // has one, and the unbounded sum put single-gap reads before the truly heavy many-gap ones: 88.8 -> 103 ms).
-    // Replayed launches against the order by true duration, configs 2 / 5 / branching: +3.6-4 % / +2.3 % / +0 %
-    // (without the term +11 % / +2.5 % / +20-24 %; unbounded +3.6-4 % / +15 % / +0 %)
+    // has one, and the unbounded sum put single-gap reads before the truly heavy many-gap ones: 88.8 -> 103 ms);
+    // q = 10 + 200 x the share of the read's solid k-mers with more than one successor or predecessor: where the graph
+    // forks, a long gap's walk carries several Trails (0.6 % of the solid k-mers on config 5, 1 % on config 2, 3.6 % on the
+    // branching workload).  DevParams.costGap*; swept on one box in profiles/r03/cost_sweep.txt.
     unsigned long long part = 0, sq = 0;
     for (uint32_t i = l; i + 1 < Rfinal; i += 64) {
       const unsigned long long g = (regS[i + 1] > regE[i] + K) ? (unsigned long long)(regS[i + 1] - (regE[i] + K)) : 0ull;
       part += 870ull * g + 20000ull;
       sq += g * g;
     }
-    unsigned long long cost = wave_sum_u64(part) + 14ull * min(wave_sum_u64(sq), 900ull * 900ull);
+    const unsigned long long gq = (unsigned long long)P.costGapQuad + ((unsigned long long)P.costGapFork * nFork) / max(m, 1ull);
+    unsigned long long cost = wave_sum_u64(part) + gq * min(wave_sum_u64(sq), (unsigned long long)P.costGapCap * P.costGapCap);
     const unsigned long long head = regS[0], eLast = regE[Rfinal - 1];
     const unsigned long long tail = (eLast + 1 < n) ? (unsigned long long)L - (eLast + K) : 0ull;
     if (head > 0 && head <= P.MAX_BORDER_LEN) cost += (unsigned long long)P.costEdgeLin * head + (unsigned long long)P.costEdgeQuad * head * head;
