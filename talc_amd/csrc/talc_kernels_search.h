@@ -550,7 +550,11 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     for (uint32_t i = l; i < Rfinal; i += 64) {
       const uint32_t s0 = regS[i], e0 = regE[i];
       const uint32_t hs = cov_hit_index(cov, s0);
-      const bool clean = ((s0 ^ e0) < (uint32_t)TALC_COV_TILE) && (e0 >= s0) && (cov_hit_index(cov, e0) - hs == e0 - s0);
+      // (the end itself must be a hit too: cov_hit_index of a position that is none counts the hits BELOW it, and a region
+      //  whose last position is no hit — defineStructure2 leaves such ends — passed the difference test alone; its pivot's
+      //  count was then read from the NEXT hit's pair: one read in 7500 of a branching transcriptome, tools/stress_branching.py)
+      const bool endHit = ((cov_word(cov, e0 >> 6).bits >> (e0 & 63u)) & 1ull) != 0ull;
+      const bool clean = ((s0 ^ e0) < (uint32_t)TALC_COV_TILE) && (e0 >= s0) && endHit && (cov_hit_index(cov, e0) - hs == e0 - s0);
       regH[i] = (hs & ~kRegClean) | (clean ? kRegClean : 0u);
     }
   }

@@ -617,6 +617,17 @@ def test_correction_across_tandem_repeats_and_cycles():
     assert (ost == 0).sum() > 200
 
 
+def test_region_whose_last_position_is_not_a_hit():
+    """defineStructure2 can leave a solid region whose END k-mer is not in the table.  Round 3's coverage layout flags a
+    region 'clean' (its pairs consecutive from its start's hit index) — a test that must look at the end position itself:
+    without that, the pivot of such a region read the NEXT hit's count (the first Trail's count, the anchor walk's first
+    level).  Found by tools/stress_branching.py (one read in 7500); this is that read and its neighbours."""
+    pair = PU.Pair(target_kmers=300_000, k=21, seed=103, synth_kw=dict(paralog_frac=0.8, paralog_div=0.04),
+                   max_nb_competing_paths=8, check_interval=4)
+    pair.upload(0)
+    _check(pair, 1300, 100)
+
+
 def test_one_context_over_batches_of_changing_shape_on_a_branching_graph():
     """The kept alignment rows of scoreBridges live in a per-wave arena that is never reset: batches of different
     longest reads (the scratch slots move) and searches of different reference lengths (the records' stride changes)

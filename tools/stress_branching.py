@@ -1,0 +1,43 @@
+"""Development tool: parity of the HIP path with the oracle on branching graphs beyond the test suite's seeds.
+    python tools/stress_branching.py [case ...]      (TALC_LIB selects the library)
+"""
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import numpy as np
+import parity_util as PU
+
+CASES = {
+    101: (dict(target_kmers=400_000, k=21, seed=101, synth_kw=dict(paralog_frac=0.6, paralog_div=0.02)), dict()),
+    102: (dict(target_kmers=400_000, k=25, seed=102, synth_kw=dict(paralog_frac=0.6, paralog_div=0.05)), dict()),
+    103: (dict(target_kmers=300_000, k=21, seed=103, synth_kw=dict(paralog_frac=0.8, paralog_div=0.04)), dict(max_nb_competing_paths=8, check_interval=4)),
+    104: (dict(target_kmers=300_000, k=23, seed=104, synth_kw=dict(paralog_frac=0.5, paralog_div=0.08)), dict(max_nb_competing_paths=3, window_size=5)),
+    105: (dict(target_kmers=500_000, k=31, seed=105, synth_kw=dict(paralog_frac=0.4, paralog_div=0.03, mixed_lengths=1)), dict()),
+}
+
+
+def main():
+    which = [int(x) for x in sys.argv[1:]] or sorted(CASES)
+    n_reads = int(os.environ.get("STRESS_READS", "1500"))
+    bad_total = 0
+    for c in which:
+        kw, pkw = CASES[c]
+        t0 = time.time()
+        pair = PU.Pair(**kw, **pkw)
+        pair.upload(0)
+        bases, offs = pair.reads(0, n_reads)
+        bad, (so, ost), (sg, gst) = PU.compare_correction(pair, bases, offs, nthreads=16, verbose=False)
+        print(c, "k", kw["k"], "reads", len(so), "status", np.bincount(ost, minlength=4).tolist(), "mismatches", len(bad), bad[:6],
+              "%.1fs" % (time.time() - t0), "lib", os.environ.get("TALC_LIB", "default"), flush=True)
+        if bad and os.environ.get("STRESS_TRACE"):
+            print("  first trace difference", PU.first_trace_diff(pair, bases, offs, bad[0]))
+        bad_total += len(bad)
+    print("TOTAL MISMATCHES", bad_total)
+    return 1 if bad_total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
