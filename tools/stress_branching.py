@@ -1,4 +1,5 @@
-"""Development tool: parity of the HIP path with the oracle on branching graphs beyond the test suite's seeds.
+"""Development tool: parity of the HIP path with the oracle beyond the test suite's seeds (branching graphs 101-105, unique
+sequence and parameter variants 201-207).
     python tools/stress_branching.py [case ...]      (TALC_LIB selects the library)
 """
 import os
@@ -16,6 +17,14 @@ CASES = {
     103: (dict(target_kmers=300_000, k=21, seed=103, synth_kw=dict(paralog_frac=0.8, paralog_div=0.04)), dict(max_nb_competing_paths=8, check_interval=4)),
     104: (dict(target_kmers=300_000, k=23, seed=104, synth_kw=dict(paralog_frac=0.5, paralog_div=0.08)), dict(max_nb_competing_paths=3, window_size=5)),
     105: (dict(target_kmers=500_000, k=31, seed=105, synth_kw=dict(paralog_frac=0.4, paralog_div=0.03, mixed_lengths=1)), dict()),
+    # unique-sequence transcriptomes, other seeds / parameters than the suite's
+    201: (dict(target_kmers=600_000, k=21, seed=201), dict()),
+    202: (dict(target_kmers=600_000, k=25, seed=202), dict(min_count=3)),
+    203: (dict(target_kmers=600_000, k=31, seed=203, synth_kw=dict(mixed_lengths=1)), dict()),
+    204: (dict(target_kmers=500_000, k=21, seed=204, junctions=True), dict()),
+    205: (dict(target_kmers=500_000, k=19, seed=205), dict(reverse=1, window_size=12)),
+    206: (dict(target_kmers=500_000, k=27, seed=206), dict(alpha=1.3, sr_error_rate=0.05, check_interval=9, max_border_length=300)),
+    207: (dict(target_kmers=400_000, k=21, seed=207, synth_kw=dict(paralog_frac=0.3, paralog_div=0.10)), dict(max_nb_competing_paths=6, max_nb_border_paths=3)),
 }
 
 
