@@ -38,6 +38,20 @@ def main():
         pair = PU.Pair(**kw, **pkw)
         pair.upload(0)
         bases, offs = pair.reads(0, n_reads)
+        n_rate = float(os.environ.get("STRESS_N", "0"))
+        if n_rate > 0:   # unknown bases in the long reads (Dna5 N: Jellyfish.cpp / Read.cpp treat the k-mers over them as absent)
+            rng = np.random.default_rng(kw["seed"])
+            bases = np.array(bases, copy=True)
+            bases[rng.random(len(bases)) < n_rate] = ord("N")
+        err_clean = float(os.environ.get("STRESS_CLEAN", "0"))
+        if err_clean > 0:   # a share of the reads replaced by their own corrected form (long clean regions, tiles full of hits)
+            o_out, o_off, _ = pair.otab.correct_batch(bases, offs, nthreads=16)
+            seqs = PU.seqs_of(bases, offs); cor = PU.seqs_of(o_out, o_off)
+            rng = np.random.default_rng(kw["seed"] + 1)
+            pick = rng.random(len(seqs)) < err_clean
+            seqs = [c if p else q for q, c, p in zip(seqs, cor, pick)]
+            bases = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+            offs = np.zeros(len(seqs) + 1, dtype=np.uint64); offs[1:] = np.cumsum([len(x) for x in seqs])
         bad, (so, ost), (sg, gst) = PU.compare_correction(pair, bases, offs, nthreads=16, verbose=False)
         print(c, "k", kw["k"], "reads", len(so), "status", np.bincount(ost, minlength=4).tolist(), "mismatches", len(bad), bad[:6],
               "%.1fs" % (time.time() - t0), "lib", os.environ.get("TALC_LIB", "default"), flush=True)
