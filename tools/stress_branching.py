@@ -43,6 +43,17 @@ def main():
             rng = np.random.default_rng(kw["seed"])
             bases = np.array(bases, copy=True)
             bases[rng.random(len(bases)) < n_rate] = ord("N")
+        trunc = int(os.environ.get("STRESS_TRUNC", "0"))
+        noise = float(os.environ.get("STRESS_NOISE", "0"))
+        if trunc > 0 or noise > 0:   # reads cut to 0..trunc bases (below K, around the 512-position tiles); extra substitutions
+            rng = np.random.default_rng(kw["seed"] + 7)
+            seqs = PU.seqs_of(bases, offs)
+            if trunc > 0:
+                seqs = [q[int(rng.integers(0, max(len(q) - 1, 1))):][:int(rng.integers(0, trunc + 1))] for q in seqs]
+            if noise > 0:
+                seqs = ["".join(("ACGT"[int(rng.integers(0, 4))] if rng.random() < noise else ch) for ch in q) for q in seqs]
+            bases = np.frombuffer("".join(seqs).encode(), dtype=np.uint8) if any(seqs) else np.zeros(0, np.uint8)
+            offs = np.zeros(len(seqs) + 1, dtype=np.uint64); offs[1:] = np.cumsum([len(x) for x in seqs])
         err_clean = float(os.environ.get("STRESS_CLEAN", "0"))
         if err_clean > 0:   # a share of the reads replaced by their own corrected form (long clean regions, tiles full of hits)
             o_out, o_off, _ = pair.otab.correct_batch(bases, offs, nthreads=16)
