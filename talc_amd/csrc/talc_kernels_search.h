@@ -1683,7 +1683,8 @@ TALC_DN void record_edge(int set_, int t_, int len0_) {
 // ------------------------------------------------------------------ one expansion step
 // Shared front half of oneMoreStep / oneMoreStepInTheDark: probe the table for the successors of
 // every Trail of the current set (one lane per Trail, 64 at a time) and tag them (tagNextNodes).
-struct StepTags { int tags; uint32_t nc[4]; double dist[4]; };
+struct StepTags { int tags; uint32_t nc[4]; };   // (a child's distance term is computed when the child is made: four
+                                                 //  doubles per lane less to carry through the step's calls)
 
 TALC_D StepTags probe_and_tag(int t, bool valid, bool complex) {
   StepTags r;
@@ -1701,7 +1702,7 @@ TALC_D StepTags probe_and_tag(int t, bool valid, bool complex) {
   }
   r.tags = (tg[0] & 0xff) | ((tg[1] & 0xff) << 8) | ((tg[2] & 0xff) << 16) | ((tg[3] & 0xff) << 24);
 #pragma unroll
-  for (int b = 0; b < 4; ++b) { r.nc[b] = cnt[b]; r.dist[b] = ds[b]; }
+  for (int b = 0; b < 4; ++b) r.nc[b] = cnt[b];
   return r;
 }
 TALC_D double shfl_f64(double v, int src) {   // src is wave-uniform
@@ -1729,8 +1730,7 @@ TALC_DNC uint32_t branch_copy(uint32_t parentBuf_, int len_, bool bridge_) {
 // BRIDGE: the step of a bridge search (a copied Trail takes its kept alignment row along; an instance of its own, so
 // that the edge step carries neither the call nor the registers held across it)
 template <bool BRIDGE>
-TALC_D void make_child(int t, int c, int b, int len, uint32_t count, double distAdd, bool inherit, uint64_t& km2,
-                       uint64_t& nm2) {
+TALC_D void make_child(int t, int c, int b, int len, uint32_t count, bool inherit, uint64_t& km2, uint64_t& nm2) {
   const uint32_t K = X.P.K;
   const uint64_t kmask = (1ULL << (2 * K)) - 1;
   const TrailRec p = tr_get(X.ia, t);
@@ -1741,7 +1741,9 @@ TALC_D void make_child(int t, int c, int b, int len, uint32_t count, double dist
   if (lane_id() == 0) {
     ((gu8)X.seqPool)[(uint64_t)cbuf * X.C.seqCap + len] = (uint8_t)b;
     TrailRec ch;
-    ch.kmer = km2; ch.nmask = nm2; ch.cnt = count; ch.score = p.score; ch.fail = p.fail; ch.dist = p.dist + distAdd;
+    // (tagNextNodes' distance term of this successor, talc_pure.h: |count of the tip - count of the successor| / sqrt(count of the tip))
+    ch.kmer = km2; ch.nmask = nm2; ch.cnt = count; ch.score = p.score; ch.fail = p.fail;
+    ch.dist = p.dist + fabs((double)p.cnt - (double)count) / sqrt((double)p.cnt);
     ch.lanc = p.lanc; ch.ranc = p.ranc; ch.buf = cbuf;
     tr_put(X.ia ^ 1, c, ch);
   }
@@ -1956,8 +1958,6 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
       // this Trail's 4 successor counts / distances, broadcast once (static register indices)
       const uint32_t pnc0 = (uint32_t)lane_get((int)mine.nc[0], tt), pnc1 = (uint32_t)lane_get((int)mine.nc[1], tt),
                      pnc2 = (uint32_t)lane_get((int)mine.nc[2], tt), pnc3 = (uint32_t)lane_get((int)mine.nc[3], tt);
-      const double pdd0 = shfl_f64(mine.dist[0], tt), pdd1 = shfl_f64(mine.dist[1], tt), pdd2 = shfl_f64(mine.dist[2], tt),
-                   pdd3 = shfl_f64(mine.dist[3], tt);
       // the last successor of this Trail inherits its sequence buffer
       const int lastI = last_successor(tags);
       if (lastI < 0) pool_free(tr_buf(X.ia, t));   // no successor: the Trail just ends
@@ -1966,12 +1966,11 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
         const int tag = (int)(int8_t)((tags >> (8 * i)) & 0xff);
         if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
         const uint32_t nc = (i == 0) ? pnc0 : (i == 1) ? pnc1 : (i == 2) ? pnc2 : pnc3;
-        const double dd = (i == 0) ? pdd0 : (i == 1) ? pdd1 : (i == 2) ? pdd2 : pdd3;
         if (nNew >= TCAP) { X.overflow |= OVF_TRAILS; continue; }
         if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
         PROF_BEGIN();
         uint64_t km2, nm2;
-        make_child<true>(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
+        make_child<true>(t, nNew, i, len, nc, i == lastI, km2, nm2);
         PROF_END(PF_CHILD);
         // checkAims (Trail.cpp:273-285): first aim whose k-mer equals the child's tip
         int hit = -1;
@@ -2113,8 +2112,6 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
       // this Trail's 4 successor counts / distances, broadcast once (static register indices)
       const uint32_t pnc0 = (uint32_t)lane_get((int)mine.nc[0], tt), pnc1 = (uint32_t)lane_get((int)mine.nc[1], tt),
                      pnc2 = (uint32_t)lane_get((int)mine.nc[2], tt), pnc3 = (uint32_t)lane_get((int)mine.nc[3], tt);
-      const double pdd0 = shfl_f64(mine.dist[0], tt), pdd1 = shfl_f64(mine.dist[1], tt), pdd2 = shfl_f64(mine.dist[2], tt),
-                   pdd3 = shfl_f64(mine.dist[3], tt);
       int counter = 0;
       const int lastI = last_successor(tags);
 #pragma nounroll
@@ -2123,12 +2120,11 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
         if (tag == TAG_NONE || tag == TAG_UNEXPECTED) continue;
         ++counter;
         const uint32_t nc = (i == 0) ? pnc0 : (i == 1) ? pnc1 : (i == 2) ? pnc2 : pnc3;
-        const double dd = (i == 0) ? pdd0 : (i == 1) ? pdd1 : (i == 2) ? pdd2 : pdd3;
         if (nNew >= TCAP) { X.overflow |= OVF_TRAILS; continue; }
         if ((uint32_t)(len + 1) > X.C.seqCap) { X.overflow |= OVF_SEQ; continue; }
         PROF_BEGIN();
         uint64_t km2, nm2;
-        make_child<false>(t, nNew, i, len, nc, dd, i == lastI, km2, nm2);
+        make_child<false>(t, nNew, i, len, nc, i == lastI, km2, nm2);
         PROF_END(PF_CHILD);
         PROF_BEGIN();
         uint32_t hv;
