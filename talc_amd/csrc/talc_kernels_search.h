@@ -1716,14 +1716,43 @@ TALC_D double shfl_f64(double v, int src) {   // src is wave-uniform
 // parent's last successor).  Returns the child's tip k-mer (wave-uniform).
 // a Trail that is not its parent's last successor: a buffer of its own with a copy of the parent's `len` bases (and, in a
 // bridge search, of the parent's kept alignment row).  A real call: branching is the rare case of the step.
+// A Trail's first len bases from buffer src to buffer dst, and (withRow: bridge searches) its kept alignment row with them
+// (row_copy's rule: row and stamps as they are).  Both are requested before either is stored: one memory round trip per
+// copied Trail instead of two.  The caller has synchronised since either was written.
+TALC_D void copy_trail(uint32_t dst, uint32_t src, int len, bool withRow) {
+  const uint32_t avail = (uint32_t)uni((int)X.rowAvail);
+  if (withRow && dst < avail && src < avail) {
+    gcu8 s1 = (gcu8)uni_ptr(X.seqPool + (uint64_t)src * X.C.seqCap);
+    gu8 d1 = (gu8)uni_ptr(X.seqPool + (uint64_t)dst * X.C.seqCap);
+    const v4u32 TALC_AS1* s2 = (const v4u32 TALC_AS1*)uni_ptr(row_of(src));
+    v4u32 TALC_AS1* d2 = (v4u32 TALC_AS1*)uni_ptr(row_of(dst));
+    const uint32_t l = (uint32_t)lane_id();
+    const uint32_t n1 = (uint32_t)len, nv1 = n1 >> 4, nv2 = (uint32_t)uni((int)X.rowStride) >> 2;   // 16-byte vectors
+    const v4u32 TALC_AS1* s1v = (const v4u32 TALC_AS1*)s1;
+    v4u32 TALC_AS1* d1v = (v4u32 TALC_AS1*)d1;
+    const v4u32 zero = {0u, 0u, 0u, 0u};
+    const v4u32 a0 = (l < nv1) ? s1v[l] : zero;
+    const uint32_t tb = (nv1 << 4) + l;
+    const uint8_t at = (tb < n1) ? s1[tb] : (uint8_t)0;
+    const v4u32 b0 = (l < nv2) ? s2[l] : zero, b1 = (l + 64u < nv2) ? s2[l + 64u] : zero;
+    if (l < nv1) d1v[l] = a0;
+    if (tb < n1) d1[tb] = at;
+    if (l < nv2) d2[l] = b0;
+    if (l + 64u < nv2) d2[l + 64u] = b1;
+    for (uint32_t i = l + 64u; i < nv1; i += 64u) d1v[i] = s1v[i];      // (Trails beyond 1 kb, references beyond 510 bases)
+    for (uint32_t i = l + 128u; i < nv2; i += 64u) d2[i] = s2[i];
+    return;
+  }
+  wave_copy(X.seqPool + (uint64_t)dst * X.C.seqCap, X.seqPool + (uint64_t)src * X.C.seqCap, (uint32_t)len);
+  if (withRow) row_copy(dst, src);
+}
 TALC_DNC uint32_t branch_copy(uint32_t parentBuf_, int len_, bool bridge_) {
   const uint32_t parentBuf = (uint32_t)uni((int)parentBuf_);
   const int len = uni(len_);
   const uint32_t cbuf = (uint32_t)pool_alloc();
   if (lane_id() == 0) g_keep.owner = 0u;   // (a buffer changes hands: a kept wavefront may be about its former contents)
   WSYNC();   // bases appended by lane 0 in earlier steps must be visible to the copying lanes
-  wave_copy(X.seqPool + (uint64_t)cbuf * X.C.seqCap, X.seqPool + (uint64_t)parentBuf * X.C.seqCap, (uint32_t)len);
-  if (uni((int)bridge_) != 0) row_copy(cbuf, parentBuf);
+  copy_trail(cbuf, parentBuf, len, uni((int)bridge_) != 0);
   return cbuf;
 }
 
@@ -1815,8 +1844,7 @@ TALC_DNC int garden(int n, int len, bool& isComplex) {
     const uint32_t src = X.gKept[i];
     TrailRec r = tr_get(ib, (int)src);
     const uint32_t nb = (uint32_t)pool_alloc();
-    wave_copy(X.seqPool + (uint64_t)nb * X.C.seqCap, X.seqPool + (uint64_t)r.buf * X.C.seqCap, (uint32_t)len);
-    if (uni((int)X.location) == LOC_INNER) row_copy(nb, r.buf);
+    copy_trail(nb, (uint32_t)uni((int)r.buf), len, uni((int)X.location) == LOC_INNER);
     r.buf = nb;
     if (l == 0) tr_put(X.ia, i, r);
   }
