@@ -130,8 +130,10 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   c.seqArena = (uint32_t)align_up(std::min<uint64_t>(arena, 0xFFFFFF00ull), 16);
   c.refCap = (uint32_t)align_up(Lm + 2ull * K + 64, 16);
   c.edgeCap = (uint32_t)align_up((uint64_t)c.seqCap + c.refCap, 16);
-  // (a region of n k-mers records at most n positions: beyond that the anchor lists cannot overflow)
-  c.anchCap = (uint32_t)std::min<uint64_t>(256ull * scale, Lm + 8);
+  // (a region of n k-mers records at most n positions: beyond that the anchor lists cannot overflow.  2048 in the first
+  //  pass already — 100 KB of a 3.4 MB slot: a nearly error-free read is ONE region of a kilobase and more, its lists hold
+  //  every forking k-mer of it, and with 256 every such read went to the retry stage's few slots)
+  c.anchCap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(256ull * scale, 2048ull), Lm + 8);
   if (c.anchCap < 8) c.anchCap = 8;
   c.fullCap = 128 * scale;
   c.fullPool = (uint32_t)align_up(std::max<uint64_t>(65536, 4ull * c.seqCap) * scale, 16);
