@@ -25,6 +25,9 @@ CASES = {
     205: (dict(target_kmers=500_000, k=19, seed=205), dict(reverse=1, window_size=12)),
     206: (dict(target_kmers=500_000, k=27, seed=206), dict(alpha=1.3, sr_error_rate=0.05, check_interval=9, max_border_length=300)),
     207: (dict(target_kmers=400_000, k=21, seed=207, synth_kw=dict(paralog_frac=0.3, paralog_div=0.10)), dict(max_nb_competing_paths=6, max_nb_border_paths=3)),
+    301: (dict(target_kmers=350_000, k=21, seed=301, synth_kw=dict(paralog_frac=0.9, paralog_div=0.015)), dict(max_nb_competing_paths=10)),
+    302: (dict(target_kmers=350_000, k=29, seed=302, synth_kw=dict(paralog_frac=0.5, paralog_div=0.03, mixed_lengths=1)), dict(check_interval=5)),
+    303: (dict(target_kmers=350_000, k=24, seed=303, junctions=True, synth_kw=dict(paralog_frac=0.4, paralog_div=0.06)), dict(min_count=3, max_nb_inner_paths=20)),
 }
 
 
