@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — corrected long-read bases/sec of the TALC hot path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
-torch.distributed.run with one rank per GPU (backend nccl = RCCL).  One "step" is one pass of the whole hot
-path (coverage probe -> structure -> path search -> reassembly) over the workload's reads, already resident
-in HBM, plus — for N>1 — the RCCL gather of the corrected records to rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  `--gpus N` IS the parallelism, as `-t N` is the
+reference's (main.cpp:242,247): run plainly with N > 1 and no WORLD_SIZE in the environment, this process stays off
+the GPU, starts the N ranks itself as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1),
+relays rank 0's one JSON line and exits with the children's worst code.  Launched by torch.distributed.run (one rank
+per GPU, backend nccl = RCCL) it is one of those ranks; a WORLD_SIZE that differs from `--gpus` is an error (exit 2).
+One "step" is one pass of the whole hot path (coverage probe -> structure -> path search -> reassembly) over the
+workload's reads, already resident in HBM, plus — for N>1 — the RCCL gather of the corrected records to rank 0.
 
 Workloads (BASELINE.json `configs`, synthetic data):
   N = 1  -> configs[1] ("config2"): 100 k ONT-like reads (~2 kb, 12 % error), 50 M-entry k=21 dump
   N > 1  -> configs[2] ("config3"): 1 M reads, 200 M-entry k=21 dump — the SAME 1 M reads whatever N is (strong
-            scaling): reads are dealt to the ranks in contiguous blocks of equal bases (talc_amd.sharding.shard_bounds,
-            replaces the OpenMP loop of main.cpp:247-308), the table is built once on rank 0 and its device image
-            broadcast to the other ranks over RCCL / xGMI (replicated per GPU, no data-path collective)
+            scaling): the input is cut into small chunks and chunk c goes to half-shard c mod 2N (rank = that / 2:
+            talc_amd.sharding.deal_chunks, replaces the OpenMP schedule(dynamic) loop of main.cpp:247-308); a rank
+            runs its two half-shards on two contexts (own stream each), so the gather of the first half's records
+            rides under the second half's search; the table is built once on rank 0 and its device image broadcast
+            to the other ranks over RCCL / xGMI (replicated per GPU, no data-path collective)
   --config 2|3|4|5 forces one of them at any N (4 = config3 + junction colours; 5 = k=31, 500 M entries, 100 k reads
   of 500 b - 20 kb); --reads / --kmers / --k override single figures (the label then says "custom").
 Rank 0 prints ONE JSON line.
@@ -42,7 +47,9 @@ CONFIGS = {
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of the node to shard the reads over (default: WORLD_SIZE, else 1); without WORLD_SIZE in the "
+                         "environment and N > 1 this process starts the N ranks itself")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="auto", help="auto (N=1: 2, N>1: 3) or one of 2, 3, 4, 5")
@@ -60,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the talc CLI (text dump + FASTA -> <o>.fa)")
     ap.add_argument("--no-map", action="store_true", help="skip the std::map leg of the CPU baseline (its table takes ~1 min to build)")
     ap.add_argument("--chunk-reads", type=int, default=0, help="N > 1: reads per dealt chunk (0 = talc_amd.sharding.chunk_size_for)")
+    ap.add_argument("--halves", type=int, default=2, choices=[1, 2],
+                    help="N > 1: half-shards (contexts) per rank; 2 = the first half's gather runs under the second half's search")
     return ap.parse_args(argv)
 
 
@@ -149,15 +158,121 @@ def emit_line(fd, text):
     os.write(fd, (text + "\n").encode())
 
 
+def launch_ranks(a, argv, child=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes.  This process never
+    imports torch or touches the GPU (a process that has must not be replaced or forked from, and the children must see
+    an untouched runtime; `child`: another command line for the ranks, for the tests); rank 0's stdout is a pipe whose one JSON line is relayed, every other rank's stdout goes to
+    stderr.  If a rank fails the others are ended (their exact PIDs) so that nobody waits in a collective for ever.
+    Exit code = the worst of the children's."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TALC_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen((child or [sys.executable, os.path.abspath(__file__)]) + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    lines = []
+
+    def drain():
+        for raw in procs[0].stdout:
+            lines.append(raw)
+
+    th = threading.Thread(target=drain, daemon=True)
+    th.start()
+    worst, failed_at = 0, None
+    ended = set()                     # ranks this launcher ended itself: their signal is not the run's result
+    live = set(range(a.gpus))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and r not in ended:
+                worst = max(worst, rc if rc > 0 else 128 - rc)
+                if failed_at is None:
+                    failed_at = time.time()
+                    print("[bench launcher] rank %d exited with %d; ending the other ranks" % (r, rc), file=sys.stderr, flush=True)
+        if failed_at is not None and live and time.time() - failed_at > 15.0:
+            for r in live - ended:
+                procs[r].kill()       # exact PIDs of this launcher's own children
+                ended.add(r)
+        time.sleep(0.05)
+    th.join(timeout=10.0)
+    for raw in lines:
+        os.write(1, raw)
+    return worst
+
+
+class HalfShard:
+    """One context + one resident batch: a rank's reads (N = 1) or one of its two halves (N > 1: virtual rank
+    2 * rank + h owns the chunks c with c mod 2N == 2 * rank + h)."""
+
+    def __init__(self, T, SH, torch, table, params, dev, synth, my_chunks, whole=None):
+        self.T, self.SH, self.torch, self.dev = T, SH, torch, dev
+        self.ctx = T.Context(table, params, dev)
+        if whole is not None:
+            bases, offs = synth.reads(0, whole)
+        else:
+            parts = [synth.reads(lo, cnt) for lo, cnt in my_chunks]
+            bases = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.uint8)
+            offs = np.zeros(sum(len(p[1]) - 1 for p in parts) + 1, dtype=np.uint64)
+            pos, k = 0, 0
+            for pb, po in parts:
+                offs[k + 1: k + len(po)] = po[1:] + np.uint64(pos)
+                pos += int(po[-1]); k += len(po) - 1
+            del parts
+        self.bases, self.offs = bases, offs
+        self.n_reads = len(offs) - 1
+        self.batch = self.ctx.batch(bases, offs)
+        self.n_bases = self.batch.n_bases
+        self.records = None     # kept device buffers (they only ever grow)
+        self.payload_buf = None
+        self.payload = None
+
+    def correct(self):
+        self.batch.correct()
+
+    def correct_and_pack(self):
+        """The half's hot path, then [n][offsets][status][records] assembled on the device for the gather."""
+        torch = self.torch
+        torch.cuda.set_device(self.dev)          # (the current device is per host thread)
+        self.batch.correct()
+        nbytes = self.batch.corrected_bytes
+        if self.records is None or self.records.numel() < max(nbytes, 1):
+            self.records = torch.empty(int(max(nbytes, 1) * 1.05) + 4096, dtype=torch.uint8, device="cuda")
+        oo_, st_ = self.batch.copy_corrected_to_device(self.records.data_ptr(), nbytes)
+        total = self.SH.header_bytes(len(st_)) + nbytes
+        if self.payload_buf is None or self.payload_buf.numel() < total:
+            self.payload_buf = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device="cuda")
+        self.payload = self.SH.pack_records_device(torch, self.records[:nbytes], oo_, st_, out=self.payload_buf)
+        torch.cuda.current_stream().synchronize()   # the payload is complete before another thread's collective reads it
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus is not None and a.gpus > 1:
+        sys.exit(launch_ranks(a, argv))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus is not None and a.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree" % (a.gpus, world),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    a.gpus = world
     out_fd = claim_stdout()
     e2e = None
-    if world == 1 and not a.no_e2e:
-        # before anything in this process touches the GPU: the CLI is a child process of a GPU-free parent
+    if world == 1 and not a.no_e2e and not under_profiler():
+        # before anything in this process touches the GPU: the CLI is a child process of a GPU-free parent (under
+        # rocprofv3 the preloaded tool has initialised the GPU already and would trace the child into the same files)
         e2e = end_to_end_cli(a, resolve_workload(a, 1))
     import torch
     dist = None
@@ -184,29 +299,24 @@ def main():
     params = T.default_params(k=w["k"], use_junctions=int(w["junctions"]))
     table, keys, counts, n_dump = build_table(T, synth, w, params, dev, rank, world, dist, torch, log)
     n_table = len(table)
-    ctx = T.Context(table, params, dev)
-    # this rank's share of the reads: the input cut into small chunks, chunk c to rank c mod N (talc_amd/sharding.py:
-    # every rank gets the same mixture of reads whatever the order of the input, as schedule(dynamic) gives the
-    # reference's threads); the rank's chunks back to back are its one resident batch
-    chunks = SH.deal_chunks(w["reads"], world, a.chunk_reads or None)
-    mine = SH.rank_chunks(chunks, world, rank)
+    # this rank's share of the reads: the input cut into small chunks, chunk c to virtual rank c mod V (V = N half-shards
+    # x N ranks; talc_amd/sharding.py: every rank gets the same mixture of reads whatever the order of the input, as
+    # schedule(dynamic) gives the reference's threads); a half-shard's chunks back to back are its one resident batch
+    halves = 1 if world == 1 else a.halves
+    vworld = world * halves
+    chunks = SH.deal_chunks(w["reads"], vworld, a.chunk_reads or None)
     if world == 1:
-        bases, offs = synth.reads(0, w["reads"])
+        shards = [HalfShard(T, SH, torch, table, params, dev, synth, None, whole=w["reads"])]
     else:
-        parts = [synth.reads(lo, cnt) for lo, cnt in mine]
-        bases = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.uint8)
-        offs = np.zeros(sum(len(p[1]) - 1 for p in parts) + 1, dtype=np.uint64)
-        pos, k = 0, 0
-        for pb, po in parts:
-            offs[k + 1: k + len(po)] = po[1:] + np.uint64(pos)
-            pos += int(po[-1]); k += len(po) - 1
-        del parts
-    n_mine = len(offs) - 1
-    batch = ctx.batch(bases, offs)
-    n_bases = batch.n_bases
+        shards = [HalfShard(T, SH, torch, table, params, dev, synth, SH.rank_chunks(chunks, vworld, rank * halves + h))
+                  for h in range(halves)]
+    ctx, batch = shards[0].ctx, shards[0].batch
+    bases, offs = shards[0].bases, shards[0].offs
+    n_mine = sum(s.n_reads for s in shards)
+    n_bases = sum(s.n_bases for s in shards)
     setup_s = time.time() - t_setup
-    log("setup %.1fs: table %d k-mers (%.2f GB on device), %d of %d reads in %d of %d chunks / %d bases resident" %
-        (setup_s, n_table, table.device_bytes / 1e9, n_mine, w["reads"], len(mine), len(chunks), n_bases))
+    log("setup %.1fs: table %d k-mers (%.2f GB on device), %d of %d reads in %d half-shard(s) of %d chunks in all / %d bases resident" %
+        (setup_s, n_table, table.device_bytes / 1e9, n_mine, w["reads"], len(shards), len(chunks), n_bases))
     # the std::map oracle table (the reference's own backend) takes about a minute to build for 54 M k-mers:
     # one host thread builds it while the GPU legs run (the box has far more cores than those legs use)
     map_job = None
@@ -214,45 +324,72 @@ def main():
         map_job = MapTableJob(w, synth, keys, counts)
 
     comm_dev = "cpu" if (world > 1 and rehearsal()) else "cuda"
-    gatherer = SH.RecordGatherer(dist, rank, world, comm_dev, dst=0) if world > 1 else None
-    keep = {"records": None, "payload": None}
-
-    def gather_records():
-        """The 'trivial RCCL gather': corrected records of every rank -> rank 0 (device tensors, torch.distributed over
-        RCCL / xGMI).  Buffers are kept from step to step; per step one small all_gather of sizes, one host read of it on
-        rank 0 and point-to-point transfers of exactly the payload bytes."""
-        nbytes = batch.corrected_bytes
-        if keep["records"] is None or keep["records"].numel() < max(nbytes, 1):
-            keep["records"] = torch.empty(int(max(nbytes, 1) * 1.05) + 4096, dtype=torch.uint8, device="cuda")
-        buf = keep["records"]
-        oo_, st_ = batch.copy_corrected_to_device(buf.data_ptr(), nbytes)
-        if world == 1:
-            return buf
-        # [n][offsets][status][records] per rank, assembled on the device; rank 0 merges by chunk index afterwards
-        keep["payload"] = SH.pack_records_device(torch, buf[:nbytes], oo_, st_, out=keep["payload"])
-        payload = keep["payload"]
-        return gatherer.gather(payload.cpu() if rehearsal() else payload)
+    gatherers = [SH.RecordGatherer(dist, rank, world, comm_dev, dst=0) for _ in shards] if world > 1 else []
 
     def one_step():
-        batch.correct()
-        return gather_records()
+        """N = 1: the hot path over the resident batch.  N > 1: the rank's two half-shards run on their own contexts
+        and streams from two host threads (the first one's launch a moment ahead: its search takes the GPU, the second
+        one's waves fill the slots it frees); this thread gathers half 0's records on rank 0 — the 'trivial RCCL gather':
+        one small all_gather of sizes, one host read of it on rank 0, point-to-point transfers of exactly the payload
+        bytes into kept buffers — while half 1 is still searching, then half 1's."""
+        if world == 1:
+            shards[0].correct()
+            return None
+        done = [threading.Event() for _ in shards]
+        errs = [None] * len(shards)
+
+        def work(i):
+            try:
+                shards[i].correct_and_pack()
+            except BaseException as e:   # noqa: BLE001 — re-raised on the main thread below
+                errs[i] = e
+            finally:
+                done[i].set()
+
+        th = []
+        for i in range(len(shards)):
+            t = threading.Thread(target=work, args=(i,))
+            t.start()
+            th.append(t)
+            if i + 1 < len(shards):
+                time.sleep(0.0005)
+        out = []
+        for i, s in enumerate(shards):
+            done[i].wait()
+            # (a failed half still takes part in the collectives below with an empty payload: no rank may hang)
+            payload = s.payload if errs[i] is None else torch.zeros(0, dtype=torch.uint8, device="cuda")
+            out.append(gatherers[i].gather(payload.cpu() if rehearsal() else payload))
+        for t in th:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        return out
+
+    tm_keys = ("encode_ms", "coverage_ms", "structure_ms", "search_ms", "emit_ms", "retry_ms")
+
+    def step_timing():
+        """Kernel times of the step just run, summed over the rank's half-shards (N > 1: the halves' kernels share the
+        GPU, so a half's event times include waiting for the other's waves: not per-kernel figures, see `roofline` at N = 1)."""
+        ts = [s.ctx.timing() for s in shards]
+        return ts, {k: sum(getattr(t, k) for t in ts) for k in tm_keys}
 
     gathered = None
     for i in range(a.warmup):
         tw = time.time()
         gathered = one_step()
-        log("warmup %d: %.2fs  %s" % (i, time.time() - tw, {k: round(v, 2) for k, v in ctx.timing().as_dict().items()}))
-    tm = {k: 0.0 for k in ("encode_ms", "coverage_ms", "structure_ms", "search_ms", "emit_ms", "retry_ms")}
+        log("warmup %d: %.2fs  %s" % (i, time.time() - tw, {k: round(v, 2) for k, v in step_timing()[1].items()}))
+    tm = {k: 0.0 for k in tm_keys}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    last = None
+    last_all = None
     for _ in range(a.steps):
         gathered = one_step()
-        last = ctx.timing()
+        last_all, t_step = step_timing()
         for k in tm:
-            tm[k] += getattr(last, k)
+            tm[k] += t_step[k]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -268,15 +405,28 @@ def main():
         total_bases = float(n_bases)
     for k in tm:
         tm[k] /= max(a.steps, 1)
+    if last_all is None:
+        last_all = step_timing()[0]
+    n_kmers = sum(t.n_kmers for t in last_all)
+    n_trail_steps = sum(t.n_trail_steps for t in last_all)
+    n_dp_cells = sum(t.n_dp_cells for t in last_all)
+    n_retried = sum(t.n_retried for t in last_all)
 
     out, oo, st = batch.fetch_corrected()
-    status_hist = np.bincount(st, minlength=5).tolist()
+    status_hist = np.bincount(st, minlength=5)
+    for s in shards[1:]:
+        status_hist = status_hist + np.bincount(s.batch.fetch_corrected()[2], minlength=5)
+    status_hist = status_hist.tolist()
     merged_reads = None
     if world > 1 and rank == 0 and gathered is not None:
-        # untimed: the gathered payloads merge into one record set in input order (rank 0's own records first)
-        seq_all, off_all, st_all = SH.merge_in_order([g.cpu().numpy() for g in gathered], chunks)
+        # untimed: the gathered payloads merge into one record set in input order (virtual rank 2 r + h = half h of rank r)
+        per_v = [None] * vworld
+        for h, per_rank in enumerate(gathered):
+            for r, g in enumerate(per_rank):
+                per_v[r * halves + h] = g.cpu().numpy()
+        seq_all, off_all, st_all = SH.merge_in_order(per_v, chunks)
         merged_reads = len(st_all)
-        # rank 0's own first chunk is the input's first chunk: its records must open the merged set
+        # rank 0's first half-shard holds the input's first chunk: its records must open the merged set
         n0 = chunks[0][1] if chunks else 0
         if (merged_reads != w["reads"] or int(off_all[-1]) != len(seq_all)
                 or seq_all[: int(oo[n0])] != out[: int(oo[n0])].tobytes() or not np.array_equal(st_all[:n0], st[:n0])):
@@ -286,11 +436,12 @@ def main():
     if rank == 0:
         value = total_bases * a.steps / elapsed
         cov_s = tm["coverage_ms"] / 1e3
-        cov_gbs = (last.n_kmers * COV_BYTES_PER_KMER / cov_s / 1e9) if cov_s > 0 else 0.0
+        cov_gbs = (n_kmers * COV_BYTES_PER_KMER / cov_s / 1e9) if cov_s > 0 else 0.0
         search_s = (tm["search_ms"] + tm["retry_ms"]) / 1e3
-        search_gbs = (last.n_trail_steps * STEP_BYTES / search_s / 1e9) if search_s > 0 else 0.0
+        search_gbs = (n_trail_steps * STEP_BYTES / search_s / 1e9) if search_s > 0 else 0.0
         lib_hash = B.source_hash()
         pmc = committed_pmc(lib_hash, w, n_mine)
+        sq = committed_sq(lib_hash, w, n_mine)
         result = {
             "metric": "corrected long-read bases/sec (whole node); k-mer-probe HBM GB/s",
             "value": value,
@@ -308,9 +459,12 @@ def main():
                 "workload": w["label"],
                 "value_is": "reads resident in HBM -> corrected records resident in HBM (the task's bench contract); SURVEY §8d's "
                             "phase (first read submitted from host memory -> last record back in host memory) is `host_to_host`, "
-                            "the whole program (text dump + FASTA -> <o>.fa) is `end_to_end`",
+                            "the whole program (text dump + FASTA -> <o>.fa) is `end_to_end`; their figures are repeated in this object",
                 "read_deal": ("all reads on the one GPU" if world == 1 else
-                              "%d chunks of <= %d reads, chunk c on rank c mod %d; rank 0 merges by chunk index" % (len(chunks), chunks[0][1], world)),
+                              "%d chunks of <= %d reads, chunk c on half-shard c mod %d (rank = half-shard / %d, %d contexts per rank); "
+                              "rank 0 merges by chunk index" % (len(chunks), chunks[0][1], vworld, halves, halves)),
+                "launched_by": "bench.py --gpus N (own child ranks)" if os.environ.get("TALC_BENCH_SELF_LAUNCHED") == "1"
+                               else ("torch.distributed.run" if world > 1 else "single process"),
                 "baseline_config": w["config"], "reads_total": w["reads"], "reads_rank0": n_mine, "k": w["k"],
                 "dump_entries": n_dump, "table_kmers": n_table, "junctions": bool(w["junctions"]),
                 "table_device_bytes": table.device_bytes, "bases_total": total_bases, "bases_rank0": n_bases,
@@ -325,39 +479,74 @@ def main():
             "roofline": {
                 "kernel": "k_coverage", "bound": "hbm", "achieved": cov_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": cov_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_coverage"),
-                "algorithmic_bytes_per_launch": last.n_kmers * COV_BYTES_PER_KMER, "launch_ms": tm["coverage_ms"],
+                "algorithmic_bytes_per_launch": n_kmers * COV_BYTES_PER_KMER, "launch_ms": tm["coverage_ms"],
                 "traffic_note": "L2-miss (fabric) bytes per launch incl. Infinity-Cache hits, separate PMC pass; null = no pass for this build",
             },
-            # the kernel that dominates the step time: the path search (integer DP + dependent probes)
-            "roofline_search": {
+            # the kernel that dominates the step time: the path search (integer DP + dependent probes).  It is LATENCY-bound
+            # (the SQ counters of the committed pass say where the waves' time goes), which is why its share of the HBM peak is small.
+            "roofline_search": dict({
                 "kernel": "k_search", "bound": "hbm", "achieved": search_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": search_gbs / HBM_PEAK_GBS, "traffic": pmc.get("k_search"),
-                "algorithmic_bytes_per_launch": last.n_trail_steps * STEP_BYTES, "launch_ms": 1e3 * search_s,
-                "trail_steps": last.n_trail_steps, "dp_cells": last.n_dp_cells,
-                "dp_gcups": (last.n_dp_cells / search_s / 1e9) if search_s > 0 else 0.0,
-            },
+                "algorithmic_bytes_per_launch": n_trail_steps * STEP_BYTES, "launch_ms": 1e3 * search_s,
+                "trail_steps": n_trail_steps, "dp_cells": n_dp_cells,
+                "dp_gcups": (n_dp_cells / search_s / 1e9) if search_s > 0 else 0.0,
+            }, **sq),
             "kernels_ms": tm,
-            "retried_reads": last.n_retried,
+            "retried_reads": n_retried,
         }
     if world == 1 and not a.no_h2h:
         h2h = host_to_host(T, table, params, dev, bases, offs, max(2, a.steps), log)
         if rank == 0:
             result["host_to_host"] = h2h
+            result["config"]["host_to_host_bases_per_s"] = h2h["value"]
+            result["config"]["host_to_host_ms_per_step"] = h2h["ms_per_step"]
     if world == 1 and not a.no_paralog and rank == 0:
-        result["paralog_workload"] = paralog_workload(T, dev, log)
+        pw = paralog_workload(T, dev, log, with_cpu=not a.no_cpu)
+        result["paralog_workload"] = pw
+        result["config"]["paralog_bases_per_s"] = pw["value"]
+        result["config"]["paralog_ms_per_step"] = pw["ms_per_step"]
+        if "cpu_value" in pw:
+            result["config"]["paralog_cpu_bases_per_s"] = pw["cpu_value"]
     if rank == 0:
         if e2e is not None:
             result["end_to_end"] = e2e
+            if "wall_s" in e2e:
+                result["config"]["end_to_end_wall_s"] = e2e["wall_s"]
+                result["config"]["end_to_end_bases_per_s"] = e2e["value"]
+                result["config"]["end_to_end_split_s"] = e2e["split_s"]
+            else:
+                result["config"]["end_to_end_error"] = e2e.get("error")
         if not a.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(a, w, synth, keys, counts, bases, offs, out, oo, st, map_job, log)
         elif not a.no_cpu:
             result["cpu_baseline"] = None   # (N > 1: the CPU baseline is rank 0's N = 1 leg, see BENCH at N = 1)
-        if gatherer is not None:
-            result["config"]["gather_host_reads_per_step_rank0"] = gatherer.host_syncs / max(a.steps + a.warmup, 1)
+        if gatherers:
+            result["config"]["gather_host_reads_per_step_rank0"] = sum(g.host_syncs for g in gatherers) / max(a.steps + a.warmup, 1)
         emit_line(out_fd, json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def under_profiler():
+    """True when a rocprofiler tool library is preloaded into this process (rocprofv3 -- python3 bench.py ...)."""
+    blob = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD",
+                                                     "ROCPROF_OUTPUT_PATH", "ROCPROF_OUTPUT_FILE_NAME"))
+    return "rocprof" in blob.lower() or any(k.startswith("ROCPROF") for k in os.environ)
+
+
+def committed_sq(lib_hash, w, reads_rank):
+    """Where `k_search`'s waves spend their time, from the SQ-counter pass committed under profiles/ (same rule as the
+    traffic: only when it was taken from this very build on this workload): wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES,
+    valu_issue_frac = VALU instructions x cycles per wave64 instruction / (SIMDs x launch cycles), waves_per_simd."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_search.json")) as f:
+            sq = json.load(f)
+        if sq.get("lib_source_hash") != lib_hash or sq.get("baseline_config") != w["config"] or sq.get("reads") != reads_rank:
+            return {}
+        return {k: sq[k] for k in ("wait_frac", "wait_inst_frac", "valu_issue_frac", "waves_per_simd", "lanes_per_valu") if k in sq}
+    except (OSError, KeyError, ValueError, TypeError):
+        return {}
 
 
 def committed_pmc(lib_hash, w, reads_rank):
@@ -420,11 +609,12 @@ def host_to_host(T, table, params, dev, bases, offs, passes, log):
                     "two contexts); table upload and FASTA parsing/writing not included"}
 
 
-def paralog_workload(T, dev, log):
+def paralog_workload(T, dev, log, with_cpu=True):
     """A side figure, never `value`: the same hot path on a transcriptome with paralog families (60 % of the transcripts
     are 5 %-diverged copies of others, K = 25) — forks and bubbles in the graph, so most searches carry several Trails
     and the time goes to scoreBridges / gardening / the generic expansion step (Explorer.cpp:546-612,689-865) instead
-    of the single-Trail fast path the headline workload lives on."""
+    of the single-Trail fast path the headline workload lives on.  `cpu_value`: the oracle on the box's host cores on the
+    first reads of the same workload (same form as `cpu_baseline`), whose records are compared with the GPU's."""
     from talc_amd.synth import Synth
     S = Synth(target_kmers=2_000_000, k=25, seed=77, paralog_frac=0.6, paralog_div=0.05)
     keys, counts = S.dump_arrays()
@@ -448,6 +638,34 @@ def paralog_workload(T, dev, log):
            "n_failed": tm.n_failed, "trail_steps": tm.n_trail_steps, "dp_cells": tm.n_dp_cells,
            "what": "20 k reads on a 2 M-base transcriptome with 60 % paralogs at 5 % divergence, K = 25 (branching graph)"}
     log("paralog workload: %.1f ms per pass of %d reads (%.3g bases/s)" % (1e3 * dt, n, nb / dt))
+    if with_cpu:
+        try:
+            g_out, g_off, g_st = b.fetch_corrected()
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            otab = O.OracleTable(O.params(k=25), O.OracleTable.FLAT)
+            otab.insert_packed(keys, counts)
+            otab.decolour()
+            n0 = min(n, 2 * threads)
+            t0 = time.perf_counter()
+            otab.correct_batch(bases[: int(offs[n0])], offs[: n0 + 1].copy(), nthreads=threads)
+            per_read = (time.perf_counter() - t0) / max(n0, 1)
+            m = int(min(n, max(4 * threads, 6.0 / max(per_read, 1e-6))))
+            sub = offs[: m + 1].copy()
+            t0 = time.perf_counter()
+            o_out, o_off, o_st = otab.correct_batch(bases[: int(sub[m])], sub, nthreads=threads)
+            cdt = time.perf_counter() - t0
+            res["cpu_value"] = float(int(sub[m]) / cdt)
+            res["cpu_threads"] = threads
+            res["cpu_cores"] = physical_cores() or threads
+            res["cpu_sample"] = "first %d reads (%d bases, %.1f s wall), oracle with the flat table, OpenMP schedule(dynamic)" % (m, int(sub[m]), cdt)
+            res["cpu_parity_with_gpu_on_sample"] = bool(int(o_off[m]) == int(g_off[m]) and np.array_equal(o_out, g_out[: int(g_off[m])])
+                                                        and np.array_equal(o_st, g_st[:m]))
+            otab.close()
+            log("paralog workload on the CPU oracle: %.3g bases/s (%d threads)" % (res["cpu_value"], threads))
+        except Exception as e:   # the side figure must never take the headline down
+            res["cpu_error"] = "%s: %s" % (type(e).__name__, e)
     b.close()
     ctx.close()
     tab.close()
@@ -485,21 +703,28 @@ class MapTableJob:
         self.q = O.params(k=w["k"], use_junctions=int(w["junctions"]))
         self.tab = O.OracleTable(self.q, O.OracleTable.MAP)
         self.build_s = None
+        self.error = None
         self._t = threading.Thread(target=self._run, args=(keys, counts), daemon=True)
         self._t.start()
 
     def _run(self, keys, counts):
-        t0 = time.time()
-        order = np.argsort(keys, kind="stable")
-        self.tab.insert_packed(keys[order], counts[order], sorted_hint=True)
-        if self.w["junctions"]:
-            jk, jc = self.synth.junction_arrays()
-            self.tab.colour_packed(jk, jc)
-        self.tab.decolour()
-        self.build_s = time.time() - t0
+        try:
+            t0 = time.time()
+            order = np.argsort(keys, kind="stable")
+            self.tab.insert_packed(keys[order], counts[order], sorted_hint=True)
+            if self.w["junctions"]:
+                jk, jc = self.synth.junction_arrays()
+                self.tab.colour_packed(jk, jc)
+            self.tab.decolour()
+            self.build_s = time.time() - t0
+        except BaseException as e:   # noqa: BLE001 — handed to table()
+            self.error = e
 
     def table(self):
+        """The finished table; raises what the build raised (a partly built table is never timed)."""
         self._t.join()
+        if self.error is not None:
+            raise self.error
         return self.tab
 
 
@@ -553,7 +778,11 @@ def cpu_baseline(a, w, synth, keys, counts, bases, offs, g_out, g_off, g_st, map
     }
     tab.close()
     if map_job is not None:
-        mtab = map_job.table()
+        try:
+            mtab = map_job.table()
+        except Exception as e:
+            res["map_error"] = "%s: %s" % (type(e).__name__, e)
+            return res
         n2, nb2, dt2, same2 = timed(mtab, 6.0, 0)
         res["map_value"] = float(nb2 / dt2)
         res["map_sample"] = ("first %d reads (%d bases, %.1f s wall) against the reference's std::map<string, pair<uint,uint>> "

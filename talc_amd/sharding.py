@@ -128,7 +128,7 @@ def pack_records_device(torch, records, offsets, status, out=None):
     total = len(head) + records.numel()
     if out is None or out.numel() < total:
         out = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=records.device)
-    out[: len(head)].copy_(torch.from_numpy(head), non_blocking=True)
+    out[: len(head)].copy_(torch.from_numpy(head))     # (a pageable temporary: the copy must not outlive it)
     out[len(head): total].copy_(records)
     return out[:total]
 
