@@ -94,6 +94,7 @@ struct talc_ctx {
   uint32_t* d_queue = nullptr;   // work-queue counters
   uint32_t* d_hist = nullptr;    // 1024 buckets of the work-queue ordering
   uint64_t* d_counters = nullptr;  // [0]=trail steps [1]=dp cells
+  uint32_t* d_thr = nullptr;       // the count model's thresholds by count (DevParams.thr)
   // device buffers of finished batches, kept for the next batch of this context (a streaming run creates and destroys
   // a batch per chunk of reads: ~20 hipMalloc / hipFree pairs each time otherwise)
   std::vector<std::pair<uint64_t, void*>> pool;   // (bytes, pointer), free
@@ -659,6 +660,14 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&c->d_hist, 1024 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&c->d_counters, (64 + 2 * 8192) * sizeof(uint64_t)));   // 64 counters + the profile build's record of every wave's last read
+  {   // isExpectedbyMyModel as two thresholds per count (Explorer.cpp:1185-1201), from the formula itself, for this ALPHA
+    const uint32_t n = 4096;
+    HIPCHK(hipMalloc((void**)&c->d_thr, 2ull * n * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_build_thresholds, dim3((n + 255) / 256), dim3(256), 0, c->stream, d.ALPHA, n, c->d_thr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    d.thr = c->d_thr; d.thrN = n; d.pad2_ = 0;
+  }
   *out = c;
   return TALC_OK;
 }
@@ -672,6 +681,7 @@ void talc_ctx_destroy(talc_ctx* c) {
   if (c->d_queue) hipFree(c->d_queue);
   if (c->d_hist) hipFree(c->d_hist);
   if (c->d_counters) hipFree(c->d_counters);
+  if (c->d_thr) hipFree(c->d_thr);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;

@@ -250,6 +250,11 @@ struct DevParams {
   uint32_t costEdgeLin, costEdgeQuad;
   // ... and the long-gap risk term: (costGapQuad + costGapFork x share of forking solid k-mers) x min(sum g^2, costGapCap^2)
   uint32_t costGapQuad, costGapFork, costGapCap, pad_;
+  // the count model's thresholds by count (device memory, built per context by k_build_thresholds from the formula itself
+  // for this ALPHA): thr[2 c] = the smallest nextc that isExpectedbyMyModel(nextc, c, false) accepts, thr[2 c + 1] = how many
+  // nextc = 0, 1, ... isExpectedbyMyModel(nextc, c, true) accepts; c < thrN (counts beyond take the formula)
+  const uint32_t* thr;
+  uint32_t thrN, pad2_;
 };
 
 }  // namespace talc

@@ -71,7 +71,7 @@ struct SearchLimits {   // (the part the search itself consults: a copy lives in
 struct SearchCaps : SearchLimits {
   uint64_t slotBytes;
   uint64_t o_setA, o_setB, o_seqPool, o_ref, o_ancL, o_ancR, o_ancPos, o_fullMeta, o_fullPoolB, o_edgeLong,
-      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak, o_wideBloom, o_rowPool, o_regH;
+      o_edgeShort, o_edgeTmp, o_dp, o_gard, o_regS, o_regE, o_wOff, o_wLen, o_weak, o_wideBloom, o_rowPool, o_regH, o_trace;
 };
 
 // The cycle filter of a LONG search (a gap of several kb: a Trail of thousands of k-mers saturates the 8192 bits the wave
@@ -166,6 +166,7 @@ static inline SearchCaps make_caps(uint32_t maxLen, uint32_t K, uint32_t scale, 
   c.o_wideBloom = take((uint64_t)WIDE_BLOOM_WORDS * 8);
   c.o_rowPool = take((uint64_t)ROW_ARENA_INTS * 4);
   c.o_regH = take((uint64_t)c.regCap * 4);
+  c.o_trace = take(64);
   c.slotBytes = align_up(o, 256);
   return c;
 }
@@ -664,12 +665,15 @@ struct EdgeCand {   // best candidate of m_longPaths / m_shortPaths kept online 
 enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN, PF_EVALFULL, PF_XDROP, PF_EXTNW,
        PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
        PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX,
-       PF_XSTAGE, PF_XLEV, PF_XSEL, PF_REFB, PF_RESULT, PF_CYQ, PF_CYX, PF_CYHIT, PF_CYFILL, PF_N };
+       PF_XSTAGE, PF_XLEV, PF_XSEL, PF_REFB, PF_RESULT, PF_CYQ, PF_CYX, PF_CYHIT, PF_CYFILL,
+       PF_SB11, PF_SB12, PF_SB21, PF_SB10, PF_SBOTHER, PF_SEGEN, PF_XCALLS, PF_XNLEV, PF_FSFORK, PF_FSDEAD, PF_FSFILT, PF_FSLIM, PF_FK1, PF_FK2, PF_FKBAIL, PF_FORK, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
                        "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
                        "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords", "#reads<0.25ms", "#reads<1ms", "#reads<4ms", \
                        "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)", "x.stage", "x.levels", "x.select", "b.ref", "b.result", \
-                       "#cyc.query", "#cyc.exact", "#cyc.found", "cyc.fill%sum"}
+                       "#cyc.query", "#cyc.exact", "#cyc.found", "cyc.fill%sum", \
+                       "#stepb 1->1", "#stepb 1->2", "#stepb 2->1", "#stepb 1->0", "#stepb other", "#stepe generic", "#xdrop calls", "#xdrop levels", \
+                       "#ffstop fork", "#ffstop deadend", "#ffstop filter", "#ffstop limit/other", "#forkstep 1 child", "#forkstep fork+deadend", "#forkstep bailed", "forkstep"}
 
 struct Wv {
   // kernel constants
@@ -702,7 +706,8 @@ struct Wv {
   // counters
   unsigned long long cells, steps;
   uint32_t overflow;
-  TraceBuf trace; bool tracing;
+  const TraceBuf* tracep;          // the debug hook's buffers (a copy in the wave's scratch slot: 40 bytes less of LDS)
+  bool tracing, traceSteps;        // this read is the traced one / ... and its steps are wanted
   // (later additions go here, at the end: the offsets of the fields above are what the hot code's LDS addressing sees)
   unsigned long long* wideBloom;   // WIDE_BLOOM_WORDS words in HBM
   int* rowPool;                    // ROW_ARENA_INTS ints in HBM (nullptr: every scoring aligns from scratch)
@@ -715,6 +720,7 @@ struct Wv {
   uint32_t LH, RH;                 // ... of the current LEFT / RIGHT region
   const uint32_t* headCov;         // the current read's kHeadCov dense counts
   uint8_t* refBuf;                 // the scratch buffer a search's reference is assembled in (ref points there, or into the read)
+  uint32_t noForkStep;             // TALC_NO_FORKSTEP=1 (k_search flags bit 1): forks go through the generic step (A/B switch)
 };
 
 enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
@@ -920,13 +926,14 @@ TALC_DNC void trace_rec(int kind, int a, int b, int c, int d, double x, const ui
   if (!X.tracing) return;
   WSYNC();
   if (lane_id() == 0) {
-    uint32_t k = atomicAdd(X.trace.nrec, 1u);
+    const TraceBuf T = *X.tracep;
+    uint32_t k = atomicAdd(T.nrec, 1u);
     uint32_t off = 0;
-    if (slen) { off = atomicAdd(X.trace.npool, slen); }
-    if (k < X.trace.cap) {
-      if (slen && off + slen <= X.trace.poolCap) for (uint32_t i = 0; i < slen; ++i) X.trace.pool[off + i] = rev ? s[slen - 1 - i] : s[i];
+    if (slen) { off = atomicAdd(T.npool, slen); }
+    if (k < T.cap) {
+      if (slen && off + slen <= T.poolCap) for (uint32_t i = 0; i < slen; ++i) T.pool[off + i] = rev ? s[slen - 1 - i] : s[i];
       else if (slen) slen = 0;
-      X.trace.recs[k] = TraceRec{kind, a, b, c, d, x, off, slen};
+      T.recs[k] = TraceRec{kind, a, b, c, d, x, off, slen};
     }
   }
   WSYNC();
@@ -1379,6 +1386,9 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
   const int qlen = len2 - S, dlen = len1 - S;
   if (qlen > 0 && dlen > 0) {
     PROF_BEGIN();
+#ifdef TALC_PROF
+    if (lane_id() == 0) g_prof[PF_XCALLS] += 1;
+#endif
     constexpr int STAGE = 3 * LDS_DP_CAP * 4;
     uint8_t TALC_AS3* stage = (uint8_t TALC_AS3*)g_dp;
     // furthest-reaching wavefronts, 1 / 2 / 4 diagonals per lane (x up to 31 / 63 / 127)
@@ -1688,6 +1698,17 @@ TALC_DN void record_edge(int set_, int t_, int len0_) {
 struct StepTags { int tags; uint32_t nc[4]; };   // (a child's distance term is computed when the child is made: four
                                                  //  doubles per lane less to carry through the step's calls)
 
+// isExpectedbyMyModel's thresholds for tagNextNodes of a tip with count `count` (talc_common.h: DevParams.thr); only
+// meaningful for count < thrN (lambda_noise <= count: ERR < 1)
+TALC_D ModelThresholds model_thresholds(uint32_t count) {
+  ModelThresholds m;
+  const uint32_t TALC_AS1* thr = (const uint32_t TALC_AS1*)X.P.thr;
+  const uint32_t c = min(count, X.P.thrN - 1u), ln = min(lambda_noise_of(count, X.P.ERR), X.P.thrN - 1u);
+  m.minExpected = thr[2u * c];
+  m.belowUnexpected = thr[2u * ln + 1u];
+  return m;
+}
+
 TALC_D StepTags probe_and_tag(int t, bool valid, bool complex) {
   StepTags r;
   uint32_t cnt[4] = {0, 0, 0, 0}, jc[4] = {0, 0, 0, 0};
@@ -1699,8 +1720,11 @@ TALC_D StepTags probe_and_tag(int t, bool valid, bool complex) {
     else { const TrailRec h = tr_get_slow(X.ia, t); km = h.kmer; nm = h.nmask; lc = h.cnt; }
     const uint32_t K = X.P.K;
     const uint64_t succN = X.dirRight ? (nm >> 1) : (nm & ((1ULL << (K - 1)) - 1));
+    // the count model's two thresholds for this Trail's count are requested before the bucket, and arrive with it
+    const ModelThresholds mt = model_thresholds(lc);
     if (!succN) dev_next_counts(X.T, km, X.dirRight, cnt, jc);
-    tag_next_nodes(X.P.ALPHA, X.P.ERR, X.P.MIN_COUNT, cnt, jc, lc, complex, tg, ds);
+    if (lc < X.P.thrN) tag_next_nodes_with(mt, X.P.ERR, X.P.MIN_COUNT, cnt, jc, lc, complex, tg, (double*)nullptr);
+    else tag_next_nodes(X.P.ALPHA, X.P.ERR, X.P.MIN_COUNT, cnt, jc, lc, complex, tg, ds);
   }
   r.tags = (tg[0] & 0xff) | ((tg[1] & 0xff) << 8) | ((tg[2] & 0xff) << 16) | ((tg[3] & 0xff) << 24);
 #pragma unroll
@@ -2037,6 +2061,9 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   bloom_flush(pend, nPend);
   const bool complex = ((uint32_t)nNew > P.MAXB);
   ++stepCounter;
+#ifdef TALC_PROF
+  if (l == 0) g_prof[(nCur == 1 && nNew == 1) ? PF_SB11 : (nCur == 1 && nNew == 2) ? PF_SB12 : (nCur == 2 && nNew == 1) ? PF_SB21 : (nCur == 1 && nNew == 0) ? PF_SB10 : PF_SBOTHER] += 1;
+#endif
   int nOut;
   if (complex & (stepCounter % P.CHECK_INTERVAL == 0)) {
     PROF_BEGIN();
@@ -2179,6 +2206,9 @@ TALC_DN int step_edge(int nCur, int len, uint32_t& stepCounter, uint32_t PATH_MA
   }
   bloom_flush(pend, nPend);
   ++stepCounter;
+#ifdef TALC_PROF
+  if (l == 0) g_prof[PF_SEGEN] += 1;
+#endif
   int nOut;
   if ((stepCounter % P.CHECK_INTERVAL == 0) || ((uint32_t)nNew >= P.MAX_BORDER_PATHS)) {
     nNew = uni(score_edges(X.ia ^ 1, nNew, len + 1, xdrop));
@@ -2217,7 +2247,7 @@ TALC_D int fast_forward_dir(int len_, uint32_t& stepCounter_, uint32_t PATH_MAXL
   const int l = lane_id();
   // (arguments of a non-inlined function arrive in vector registers: make every one of them scalar)
   const bool edge = uni((int)edge_) != 0;
-  if (uni((int)(X.tracing && X.trace.steps)) != 0) return 0;
+  if (uni((int)(X.traceSteps)) != 0) return 0;
   const TrailRec r0 = tr_get(X.ia, 0);
   if (uni64(r0.nmask) != 0ull) return 0;
   const uint32_t K = (uint32_t)uni((int)P.K), MINC = (uint32_t)uni((int)P.MIN_COUNT), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
@@ -2363,7 +2393,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   const DevParams& P = X.P;
   const int l = lane_id();
   const bool edge = uni((int)edge_) != 0;
-  if (uni((int)(X.tracing && X.trace.steps)) != 0) return 0;
+  if (uni((int)(X.traceSteps)) != 0) return 0;
   const TrailRec r0 = tr_get(X.ia, 0);
   if (uni64(r0.nmask) != 0ull) return 0;
   const uint32_t K = (uint32_t)uni((int)P.K), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
@@ -2417,6 +2447,7 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
   const uint32_t laneOff = (l < TALC_WALK_LEVELS) ? (uint32_t)(2 + (l >> 1)) : (l == TALC_WALK_LEVELS + 1 ? 1u : 0u);
   const uint32_t laneShift = (l < TALC_WALK_LEVELS && (l & 1)) ? 16u : 0u;
   const int lj = min(l, TALC_WALK_LEVELS - 1);                // shift amounts stay in range on the idle lanes
+  const uint32_t laneSingle = (l < TALC_WALK_LEVELS) ? kWalkSingle : 0u;
   uint64_t key = dirRight ? (kmer & m1) : (kmer >> 2);
   uint32_t hh = (uint32_t)(table_hash(key) >> 32);
   PROF_END2(PF_FFENTRY);
@@ -2445,9 +2476,19 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
     if (!found) break;
     PROF_BEGIN();
     const uint32_t lev = (e >> laneShift) & 0xFFFFu, top = lev & kWalkTopNone;
+#ifdef TALC_PROF
+    {   // why the walk will stop in this record, if it does: the first level that is not "single"
+      const unsigned long long pm = ballot64((l < TALC_WALK_LEVELS) && (lev & kWalkSingle) != 0u);
+      const int j0 = __builtin_ctzll(~pm);
+      if (j0 < TALC_WALK_LEVELS && j0 < maxSteps - done) {
+        const uint32_t t0 = (uint32_t)lane_get((int)top, j0);
+        if (l == 0) g_prof[(t0 >= X.P.MIN_COUNT) ? PF_FSFORK : PF_FSDEAD] += 1;
+      }
+    }
+#endif
     // levels that are "exactly one successor with count >= MIN_COUNT" (decided at upload for the table's MIN_COUNT, which
     // is this context's), from level 0 up to the first that is not
-    const unsigned long long passMask = ballot64((l < TALC_WALK_LEVELS) && (lev & kWalkSingle) != 0u);
+    const unsigned long long passMask = ballot64((lev & laneSingle) != 0u);   // (a plain compare: the ballot is its lane mask)
     int nOK = min(__builtin_ctzll(~passMask), maxSteps - done);
     if (nOK == 0) break;
     // lane j's tip after its step: the current tip shifted by j+1 bases, with the bases of levels 0..j
@@ -2467,6 +2508,8 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
       ePre = wtab[slotN * 8 + laneOff];
     }
     // possible cycle inside the record: the same hash on a lower lane
+    // (gfx950 has no DPP form of the vector compares — "dpp variant of this instruction is not supported" — so each
+    //  distance stays a copy, a DPP move and a compare)
     bool dup = dpp_row_shr<1>(hv, ~hv) == hv;
     dup |= dpp_row_shr<2>(hv, ~hv) == hv;
     dup |= dpp_row_shr<3>(hv, ~hv) == hv;
@@ -2500,6 +2543,9 @@ TALC_D int fast_forward_walk(int len_, uint32_t& stepCounter_, uint32_t PATH_MAX
       const unsigned long long am = ballot64((l < nAims) && (g_aimK[l < AIMS_LDS ? l : 0] == kmH) && (g_aimN[l < AIMS_LDS ? l : 0] == 0ull));
       if (am != 0ull) aimIdx = (int)__builtin_ctzll(am);   // checkAims takes the first aim that matches (Trail.cpp:273-285)
     }
+#ifdef TALC_PROF
+    if (hitLevel < nOK && aimIdx < 0 && l == 0) g_prof[PF_FSFILT] += 1;
+#endif
     nOK = min(nOK, hitLevel);
     const int nTake = nOK + (aimIdx >= 0 ? 1 : 0);
     if (nTake == 0) break;
@@ -2578,6 +2624,156 @@ TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH
                                 : fast_forward_walk<false, false>(len, stepCounter, PATH_MAXLENGTH, edge);
   }
   [[clang::musttail]] return fast_forward_steps(len, stepCounter, PATH_MAXLENGTH, edge);
+}
+
+// ------------------------------------------------------------------ a fork whose second branch ends at once
+// The walk above stops at every tip that has more than one successor in the table.  On a transcriptome whose dump
+// carries sequencing-error k-mers (counts 2-3 beside the true k-mer's 30) nearly all of those stops are of two kinds:
+//   (a) tagNextNodes (Explorer.cpp:1226-1298) follows only ONE of the successors — the step is a plain step after all;
+//   (b) it follows two, and at the NEXT step one of the two children has no successor to follow while the other has
+//       exactly one: oneMoreStep (Explorer.cpp:546-612) makes two Trails, drops one a step later, and the search is back
+//       to one Trail — two generic steps (~15 000 wave-cycles each: a probe, two children with a buffer copy, aim and
+//       cycle tests, set swaps) for what is two plain steps of the surviving Trail.
+// fork_step decides both cases from ONE round of probes — lane 4 the tip's successor bucket, lanes 0-3 the buckets of
+// its four possible children, in flight together — with the reference's own tagging (tag_next_nodes, the function the
+// generic step uses), and commits the one or two steps exactly as the generic steps would leave the surviving Trail:
+// k-mer, count, the distance terms |c - n| / sqrt(c) in path order (make_child's expression), bases, step counter, the
+// Trail-step statistic (1 + 2 probes for case b).  Whatever is not exactly (a) or (b) with every involved k-mer absent
+// from the search's filter (no aim, no possible cycle) returns 0 and the generic step takes the step from the unchanged
+// state: more than two followed successors, a dead end, both children alive, limits about to be reached, scoring due
+// (MAX_NB_BRANCHES below 2), a k-mer with N, the step trace.  Bridge searches only: an edge search scores two Trails.
+// The child that ends is not entered in the filter (the generic step would enter it): the filter stays a superset of
+// the live Trail's own k-mers, which is all ThinkIveAlreadyGotThere's exact search relies on.
+TALC_DN int fork_step(int len_, uint32_t sc_, uint32_t PMAX_) {
+  PROF_DECL;
+  PROF_BEGIN();
+  const DevParams& P = X.P;
+  const int l = lane_id();
+  const int len = uni(len_);
+  const uint32_t sc = (uint32_t)uni((int)sc_), PMAX = (uint32_t)uni((int)PMAX_);
+  if (uni((int)X.traceSteps) != 0 || uni((int)X.noForkStep) != 0) return 0;
+  if ((uint32_t)uni((int)P.MAXB) < 2u || (uint32_t)uni((int)P.MAX_INNER_PATHS) < 2u) return 0;
+  const TrailRec r0 = tr_get(X.ia, 0);
+  if (uni64(r0.nmask) != 0ull) return 0;
+  const uint32_t K = (uint32_t)uni((int)P.K), MINC = (uint32_t)uni((int)P.MIN_COUNT), seqCap = (uint32_t)uni((int)X.C.seqCap);
+  if (!(sc < PMAX) || (uint32_t)len + 1u > seqCap) return 0;
+  const bool dirRight = uni(X.dirRight) != 0;
+  const uint64_t kmask = (1ULL << (2 * K)) - 1, m1 = (1ULL << (2 * (K - 1))) - 1;
+  const uint64_t kmer = uni64(r0.kmer);
+  const uint32_t cnt = (uint32_t)uni((int)r0.cnt);
+  if (cnt >= (uint32_t)uni((int)P.thrN)) return 0;   // (a count beyond the threshold table: the generic step has the formula)
+  auto child_of = [&](uint64_t km, uint32_t b) -> uint64_t {
+    return dirRight ? (((km << 2) | (uint64_t)b) & kmask) : (((uint64_t)b << (2 * (K - 1))) | (km >> 2));
+  };
+  auto get64 = [&](uint64_t v, int src) -> uint64_t {
+    return ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)lane_get((int)(uint32_t)v, src);
+  };
+  // ---- one round of loads: the count model's thresholds for the tip's count, lane 4 the tip's successor bucket, lanes
+  // b < 4 the HOME bucket of child b's successors (a child that is not followed is never looked at again; one that is
+  // nearly always sits in its home bucket)
+  const ModelThresholds mtTip = model_thresholds(cnt);
+  const uint64_t kmMine = (l == 4) ? kmer : child_of(kmer, (uint32_t)(l & 3));
+  const uint64_t keyMine = dirRight ? (kmMine & m1) : (kmMine >> 2);
+  const Bucket* tab = dirRight ? X.T.right : X.T.left;
+  const uint64_t cap = X.T.capacity;
+  const uint64_t hMine = table_hash(keyMine);
+  uint64_t slotMine = table_slot(hMine, cap);
+  BucketRegs br;
+  br.key = kEmptyKey; br.cnt[0] = br.cnt[1] = br.cnt[2] = br.cnt[3] = 0u; br.jc01 = br.jc23 = 0u;
+  if (l <= 4) br = load_bucket(tab + slotMine);
+  bool okTip = false;
+  if (l == 4) okTip = probe_bucket_from(tab, cap, keyMine, slotMine, br);
+  uint32_t tc[4], tj[4];
+  {
+    const uint32_t found4 = (uint32_t)lane_get((int)okTip, 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tc[i] = found4 ? (uint32_t)lane_get((int)br.cnt[i], 4) : 0u;
+      tj[i] = found4 ? (uint32_t)lane_get((int)br.jc(i), 4) : 0u;
+    }
+  }
+  int tg[4];
+  tag_next_nodes_with(mtTip, P.ERR, MINC, tc, tj, cnt, false, tg, (double*)nullptr);   // (complex: one Trail never exceeds MAX_NB_BRANCHES >= 2)
+  int fm = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (tg[i] != TAG_NONE && tg[i] != TAG_UNEXPECTED) fm |= 1 << i;
+  fm = uni(fm);
+  const int nF = __builtin_popcount((unsigned)fm);
+  int taken = 0;
+  if (nF == 1 || nF == 2) {
+    // (the walk also stops at a tip with ONE successor when the filter has seen that successor — an aim, a possible
+    //  cycle: the query below then says "maybe" and the generic step takes it, as it must)
+    // aim / cycle: the followed children against the search's filter (it holds the aims, init_first_trail); the hash of a
+    // k-mer's successor key is the hash its bucket was addressed with
+    const bool mine = (l < 4) && (((fm >> l) & 1) != 0);
+    const uint32_t hvMine = (uint32_t)(hMine >> 32);
+    bool maybe = false;
+    if (mine) { uint32_t hq; maybe = bloom_query(kmMine, 0ull, hq); }
+    const int iA = __builtin_ctz((unsigned)fm);
+    int iS = iA, bC = 0;
+    uint32_t cS = 0, cC = 0, hvS = 0, hvC = 0;
+    uint64_t kmS = 0, kmC = 0;
+    bool ok = ballot64(mine && maybe) == 0ull;
+    if (ok && nF == 2) {
+      ok = (sc + 1u < PMAX) && ((uint32_t)len + 2u <= seqCap);
+      if (ok) {
+        // the step after the fork: a child with NO successor in the table ends there, a child with exactly ONE is followed
+        // whatever the count model says (tagNextNodes: counter == 1, Explorer.cpp:1251); anything else is not this case
+        bool found = false;
+        if (mine) found = probe_bucket_from(tab, cap, keyMine, slotMine, br);
+        uint32_t nSucc = 0, which = 0, cSucc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (found && br.cnt[i] >= MINC) { ++nSucc; which = (uint32_t)i; cSucc = br.cnt[i]; }
+        const int iB = __builtin_ctz((unsigned)(fm & (fm - 1)));
+        const int nA = lane_get((int)nSucc, iA), nB = lane_get((int)nSucc, iB);
+        ok = ((nA == 1) & (nB == 0)) | ((nA == 0) & (nB == 1));
+        if (ok) {
+          iS = nA ? iA : iB;
+          bC = lane_get((int)which, iS);
+          cC = (uint32_t)lane_get((int)cSucc, iS);
+        }
+      }
+    }
+    if (ok) {
+      cS = (iS == 0) ? tc[0] : (iS == 1) ? tc[1] : (iS == 2) ? tc[2] : tc[3];
+      kmS = get64(kmMine, iS);
+      hvS = (uint32_t)lane_get((int)hvMine, iS);
+      if (nF == 2) {
+        kmC = child_of(kmS, (uint32_t)bC);
+        ok = !bloom_query(kmC, 0ull, hvC);
+        hvC = (uint32_t)uni((int)hvC);
+      }
+    }
+    if (ok) {
+      // ---- commit: the surviving Trail as the generic steps would leave it
+      const uint32_t wm = (uint32_t)uni((int)X.wideMask);
+      gu8 seq = (gu8)uni_ptr(X.seqPool + (uint64_t)r0.buf * X.C.seqCap);
+      if (l == 0) {
+        TrailRec r = r0;
+        seq[len] = (uint8_t)iS;
+        r.dist = r0.dist + fabs((double)cnt - (double)cS) / sqrt((double)cnt);
+        r.kmer = kmS; r.cnt = cS;
+        atomicOr(&g_bloom[hvS >> 25], (1ull << ((hvS >> 19) & 63u)) | (1ull << ((hvS >> 13) & 63u)));
+        if (wm != 0u) wide_or(X.wideBloom + wide_word(hvS, wm), wide_bits(hvS));
+        if (nF == 2) {
+          seq[len + 1] = (uint8_t)bC;
+          r.dist = r.dist + fabs((double)cS - (double)cC) / sqrt((double)cS);
+          r.kmer = kmC; r.cnt = cC;
+          atomicOr(&g_bloom[hvC >> 25], (1ull << ((hvC >> 19) & 63u)) | (1ull << ((hvC >> 13) & 63u)));
+          if (wm != 0u) wide_or(X.wideBloom + wide_word(hvC, wm), wide_bits(hvC));
+        }
+        tr_put(X.ia, 0, r);
+      }
+      taken = nF;
+      X.steps += (nF == 2) ? 3ull : 1ull;   // Trails probed: one at the fork, two at the step after it
+      LSYNC();
+    }
+  }
+#ifdef TALC_PROF
+  if (l == 0) g_prof[taken == 1 ? PF_FK1 : taken == 2 ? PF_FK2 : PF_FKBAIL] += 1;
+#endif
+  PROF_END(PF_FORK);
+  return taken;
 }
 
 // first Trail of a search: the start anchor (Trail.cpp:57-65)
@@ -2732,12 +2928,15 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
         PROF_BEGIN2(); len += uni(fast_forward(len, stepCounter, PATH_MAXLENGTH, false)); PROF_END2(PF_FFWD);
         if (X.ffPopped) { X.ffPopped = false; nCur = 0; break; }   // its last step recorded a bridge and ended the Trail
         if (!(stepCounter < PATH_MAXLENGTH)) break;
+        // where the walk stopped: a fork whose second branch ends at once is two more plain steps (fork_step)
+        const int fs = uni(fork_step(len, stepCounter, PATH_MAXLENGTH));
+        if (fs > 0) { len += fs; stepCounter += (uint32_t)fs; continue; }
       }
       PROF_BEGIN2();
       nCur = uni(step_bridge(nCur, len, stepCounter));
       PROF_END2(PF_STEPB);
       ++len;
-      if (uni((int)(X.tracing && X.trace.steps))) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
+      if (uni((int)(X.traceSteps))) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
     }
     if (X.overflow) return false;
     if (X.nFull > 0) {
@@ -2898,7 +3097,7 @@ TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& w
       nCur = uni(step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop));
       PROF_END2(PF_STEPE);
       ++len;
-      if (uni((int)(X.tracing && X.trace.steps)))
+      if (uni((int)(X.traceSteps)))
         trace_rec(TR_STEP, (int)stepCounter, nCur, X.nEdges, xdrop, 0.0, nullptr, 0, false);
     }
     if (X.overflow) return false;
@@ -2964,6 +3163,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.wideBloom = (unsigned long long*)(slot + C.o_wideBloom); X.wideMask = 0;
   X.rowPool = (flags & 1u) ? nullptr : (int*)(slot + C.o_rowPool); X.rowStride = 0; X.rowAvail = 0;   // (flags bit 0: TALC_NO_ROWS)
   X.launchStamp = launchStamp;
+  X.noForkStep = (flags >> 1) & 1u;
   X.searchNo = 16u;   // (stamps below 16 << 12 could be matrix values)
   {
     uint8_t* g = slot + C.o_gard;
@@ -2976,7 +3176,8 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.regS = (uint32_t*)(slot + C.o_regS); X.regE = (uint32_t*)(slot + C.o_regE); X.regH = (uint32_t*)(slot + C.o_regH);
   X.wOff = (uint32_t*)(slot + C.o_wOff); X.wLen = (uint32_t*)(slot + C.o_wLen);
   X.weak = slot + C.o_weak;
-  X.trace = trace;
+  if (l == 0) *(TraceBuf*)(slot + C.o_trace) = trace;
+  X.tracep = (const TraceBuf*)(slot + C.o_trace);
   unsigned long long totCells = 0, totSteps = 0;
   PROF_DECL2;
 #ifdef TALC_PROF
@@ -3016,6 +3217,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     X.read = codes + rb; X.L = L; X.n = L >= P.K ? L - P.K + 1 : 0; X.cov = covAll + koff[r]; X.covw = covWords + cov_word_base(koff[r], r); X.headCov = headCovAll + (uint64_t)r * kHeadCov; X.lambda = st.lambda;
     X.cells = 0; X.steps = 0; X.overflow = 0; X.complexRegion = false; X.ffPopped = false;
     X.tracing = (trace.recs != nullptr) && (r == traceRead);
+    X.traceSteps = X.tracing && (trace.steps != 0);
 
     if (st.status != TALC_READ_CORRECTED || st.overflow) {
       // not corrected: pass the (encoded) read through (main.cpp:310 writes mySeqs[r] unchanged)
@@ -3168,7 +3370,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     if (totCells) atomicAdd((unsigned long long*)&counters[1], totCells);
 #ifdef TALC_PROF
     g_prof[PF_TOTAL] = (uint32_t)(__builtin_amdgcn_s_memtime() - _pf_k0);
-    g_prof[PF_XSTAGE] = g_wprof[0]; g_prof[PF_XLEV] = g_wprof[1]; g_prof[PF_XSEL] = g_wprof[2];
+    g_prof[PF_XSTAGE] = g_wprof[0]; g_prof[PF_XLEV] = g_wprof[1]; g_prof[PF_XSEL] = g_wprof[2]; g_prof[PF_XNLEV] = g_wprof[3];
     {   // wave utilisation of the launch: sum of the waves' lifetimes against (last end - first start) x waves
       const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
       atomicAdd((unsigned long long*)&counters[61], r1 - _pf_r0);   // (counters[2 .. 2 + PF_N) are the categories)
@@ -3221,6 +3423,23 @@ __global__ void __launch_bounds__(1024) k_order_scan(uint32_t* __restrict__ hist
 __global__ void k_order_scatter(const ReadState* __restrict__ state, uint32_t n, uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) order[atomicAdd(&cursor[order_bucket(state[r])], 1u)] = r;
+}
+
+// ==================================================================== the count model's thresholds (DevParams.thr)
+// One thread per count c < n: both predicates of isExpectedbyMyModel are monotone in nextc, so each is one number — found
+// by bisection on the predicate ITSELF (the formula as the device evaluates it), not by solving it: the table cannot
+// disagree with the formula it replaces.
+__global__ void k_build_thresholds(double ALPHA, uint32_t n, uint32_t* __restrict__ thr) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  uint32_t lo = 0, hi = 0x7FFFFFFFu;   // smallest nextc accepted by (nextc, c, false): "nextc >= bound"
+  if (!is_expected_by_model(ALPHA, hi, c, false)) lo = hi = 0xFFFFFFFFu;
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (is_expected_by_model(ALPHA, mid, c, false)) hi = mid; else lo = mid + 1; }
+  thr[2u * c] = lo;
+  lo = 0; hi = 0x7FFFFFFFu;            // number of nextc accepted by (nextc, c, true): "nextc <= bound"
+  if (is_expected_by_model(ALPHA, hi, c, true)) lo = hi = 0xFFFFFFFFu;
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (!is_expected_by_model(ALPHA, mid, c, true)) hi = mid; else lo = mid + 1; }
+  thr[2u * c + 1u] = lo;               // the first nextc that is NOT accepted = how many are
 }
 
 // ==================================================================== k_pack

@@ -56,22 +56,38 @@ enum : int { TAG_EXPECTED = 0, TAG_UNEXPECTED = 1, TAG_BREAKPOINT = 7, TAG_NONE 
 // Returns the number of tags produced (0 when no successor reaches MIN_COUNT, else 4).
 // dist[b] is only computed for successors present in the table (count >= MIN_COUNT): the
 // reference only ever reads it for successors that become Trails (Explorer.cpp:570-574,641-646),
-// and those all have count >= MIN_COUNT.
-TALC_HD int tag_next_nodes(double ALPHA, double ERR, uint32_t MINC, const uint32_t cnt[4], const uint32_t jc[4],
-                           uint32_t count, bool complex, int tags[4], double dist[4]) {
+// and those all have count >= MIN_COUNT.  dist may be null (the device's steps compute a child's term when they make it).
+// The count model enters through `model(nextc, cc, classeUnexpected)` = isExpectedbyMyModel: the formula itself
+// (ModelFormula), or its two thresholds for this call's `count` and lambda_noise read from a table (ModelThresholds,
+// device: k_build_thresholds) — tagNextNodes only ever asks (x, count, false) and (x, lambda_noise, true).
+struct ModelFormula {
+  double ALPHA;
+  TALC_HD bool operator()(uint32_t nextc, uint32_t cc, bool classeUnexpected) const { return is_expected_by_model(ALPHA, nextc, cc, classeUnexpected); }
+};
+// minExpected = the smallest nextc with isExpectedbyMyModel(nextc, count, false); belowUnexpected = the number of
+// nextc = 0, 1, 2, ... with isExpectedbyMyModel(nextc, lambda_noise, true) (both predicates are monotone in nextc)
+struct ModelThresholds {
+  uint32_t minExpected, belowUnexpected;
+  TALC_HD bool operator()(uint32_t nextc, uint32_t, bool classeUnexpected) const { return classeUnexpected ? (nextc < belowUnexpected) : (nextc >= minExpected); }
+};
+TALC_HD uint32_t lambda_noise_of(uint32_t count, double ERR) { return (uint32_t)(int)((double)count * ERR); }
+
+template <class Model>
+TALC_HD int tag_next_nodes_with(const Model& model, double ERR, uint32_t MINC, const uint32_t cnt[4], const uint32_t jc[4],
+                                uint32_t count, bool complex, int tags[4], double* dist) {
   int counter = 0;
   uint32_t lambda_noise = 0, nbExpected = 0, nbBreakpoints = 0, nbUnexpected = 0;
-  for (int i = 0; i < 4; ++i) { tags[i] = TAG_NONE; dist[i] = 0; if (cnt[i] >= MINC) counter++; }
+  for (int i = 0; i < 4; ++i) { tags[i] = TAG_NONE; if (dist) dist[i] = 0; if (cnt[i] >= MINC) counter++; }
   if (counter == 0) return 0;
-  lambda_noise = (uint32_t)(int)((double)count * ERR);
+  lambda_noise = lambda_noise_of(count, ERR);
   for (int b = 0; b < 4; ++b) {
     const uint32_t nextc = cnt[b];
     if (nextc >= MINC) {
-      dist[b] = fabs((double)count - (double)nextc) / sqrt((double)count);
-      if (is_expected_by_model(ALPHA, nextc, count, false) || (counter == 1)) {
+      if (dist) dist[b] = fabs((double)count - (double)nextc) / sqrt((double)count);
+      if (model(nextc, count, false) || (counter == 1)) {
         tags[b] = TAG_EXPECTED; ++nbExpected;
       } else if (lambda_noise >= MINC) {
-        if (!is_expected_by_model(ALPHA, nextc, lambda_noise, true) || (jc[b] > 0)) { tags[b] = TAG_BREAKPOINT; ++nbBreakpoints; }
+        if (!model(nextc, lambda_noise, true) || (jc[b] > 0)) { tags[b] = TAG_BREAKPOINT; ++nbBreakpoints; }
         else { tags[b] = TAG_UNEXPECTED; ++nbUnexpected; }
       } else {
         tags[b] = TAG_BREAKPOINT; ++nbBreakpoints;
@@ -92,9 +108,13 @@ TALC_HD int tag_next_nodes(double ALPHA, double ERR, uint32_t MINC, const uint32
         if (cnt[index] < cnt[i]) index = i;
       }
     }
-    if (!is_expected_by_model(ALPHA, (uint32_t)sum, lambda_noise, true)) tags[index] = TAG_BREAKPOINT;
+    if (!model((uint32_t)sum, lambda_noise, true)) tags[index] = TAG_BREAKPOINT;
   }
   return 4;
+}
+TALC_HD int tag_next_nodes(double ALPHA, double ERR, uint32_t MINC, const uint32_t cnt[4], const uint32_t jc[4],
+                           uint32_t count, bool complex, int tags[4], double dist[4]) {
+  return tag_next_nodes_with(ModelFormula{ALPHA}, ERR, MINC, cnt, jc, count, complex, tags, dist);
 }
 
 // ------------------------------------------------------------------ libstdc++ std::sort, restated

@@ -57,7 +57,9 @@ TALC_D int bcast_i32(int v, int src) { return __shfl(v, src, 64); }
 // whole-wave lane moves as one DPP VALU op (gfx9 wave_shr:1 / wave_ror:1) instead of ds_bpermute:
 // lane L receives lane L-1's value; lane 0 keeps `self` (shr) or receives lane 63's (ror).
 TALC_D int lane_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
-TALC_D int lane_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C, 0xF, 0xF, false); }
+// (a rotation gives every lane a source, so the "old" operand is never used: 0 with bound_ctrl lets the compiler drop the
+//  copy it would otherwise make for the tied operand — one VALU instruction per rotation, two per wavefront level)
+TALC_D int lane_ror1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xF, 0xF, true); }
 // value of lane `src` for a wave-uniform src: v_readlane (SGPR result) instead of ds_bpermute
 TALC_D int lane_get(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
 // tell the compiler a value is wave-uniform so that everything derived from it runs on the scalar unit
@@ -74,7 +76,9 @@ TALC_D unsigned long long uni64(unsigned long long v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
-TALC_D unsigned long long ballot64(bool p) { return __ballot(p); }
+// (the ballot builtin, not __ballot(): that one compares the predicate widened to an int with zero — a v_cndmask and a v_cmp
+//  per call on top of the compare that made the predicate; the builtin hands back the compare's own lane mask)
+TALC_D unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // dst[0..n) = src[0..n); both 16-byte aligned, n arbitrary (tail by bytes).
 TALC_D void wave_copy(uint8_t* __restrict__ dst_, const uint8_t* __restrict__ src_, uint32_t n) {
@@ -495,7 +499,7 @@ TALC_D void wave_edit_lcs_reg(const uint8_t* __restrict__ H_, int n, const uint8
 // full sweep of the band per anti-diagonal in the DP formulation.
 // Returns 1 if the seed moves, 0 if not, -1 if x needs more than 64*NR-1 diagonals or the segments do
 // not fit the LDS stage (the caller falls back to the anti-diagonal DP).
-TALC_D int lane_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x134, 0xF, 0xF, false); }
+TALC_D int lane_rol1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xF, 0xF, true); }
 TALC_D int wave_min_i32(int v) {
   TALC_WAVE_REDUCE(v, min, INT_MAX);
   return __builtin_amdgcn_readlane(v, 63);
@@ -823,6 +827,9 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   }
   cells += work;
   WPROF_ADD(1, _t1);
+#ifdef TALC_PROF
+  if (eLast >= eStart) g_wprof[3] += (uint32_t)(eLast - eStart + 1);
+#endif
   const unsigned long long _t2 = WPROF_T();
   if (cornerHit) { extCols = qlen; extRows = dlen; extScore = -cornerE; return 1; }
   if (toLevel >= 0 && toLevel < x) {   // hand over to the wider instance
