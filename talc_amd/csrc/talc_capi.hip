@@ -277,7 +277,12 @@ int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts,
   for (long i = 0; i < (long)n; ++i) kept += counts[i] >= p->min_count ? 1 : 0;
   talc_table* t = new talc_table();
   t->h.p = *p;
-  t->h.capacity = kept * 2 + 64;   // load factor <= 0.5 (HostTable::allocate)
+  {   // (sparser than load 0.5 when the device has the room: HostTable::capacity_for)
+    hipDeviceProp_t prop;
+    uint64_t devBytes = 0;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) devBytes = (uint64_t)prop.totalGlobalMem;
+    t->h.capacity = HostTable::capacity_for(kept, devBytes);
+  }
   if (t->h.capacity >= (1ULL << 32)) { delete t; return fail(TALC_ERR_NOMEM, "table of %llu k-mers exceeds 2^32 buckets", (unsigned long long)kept); }
   t->hostValid = false;
   const uint64_t cap = t->h.capacity, bytes = cap * sizeof(Bucket);

@@ -48,8 +48,24 @@ struct HostTable {
     return table_home(key, cap);
   }
 
+  // Buckets per table for nKept stored k-mers.  Load factor <= 0.5 always; a table built for a GPU whose memory it leaves
+  // mostly idle is made sparser — 4 or 3 buckets per k-mer — because what a lookup costs is the number of lines its
+  // linear-probing chain touches, and the random-read rate of the memory system is what k_coverage is bound by (a 217 M
+  // k-mer table: 38.3 % of the HBM peak at 2 buckets per k-mer, 39.6 % at 2.7, 42.2 % at 4; k_search -1.7 %;
+  // profiles/r04).  deviceBytes = 0 (a host table): 2.  The four tables of a copy (two bucket tables, two walk tables:
+  // 128 bytes per bucket) may take 40 % of the device at the density chosen.  TALC_TABLE_SLOTS_X10 overrides (20 .. 80).
+  static uint64_t capacity_for(uint64_t nKept, uint64_t deviceBytes = 0) {
+    uint64_t x10 = 20;
+    for (uint64_t cand : {40ull, 30ull}) {
+      if (deviceBytes && (nKept * cand / 10) * 128ull <= deviceBytes / 10 * 4) { x10 = cand; break; }
+    }
+    if (const char* e = getenv("TALC_TABLE_SLOTS_X10")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 20 && v <= 80) x10 = v; }
+    uint64_t cap = nKept * x10 / 10 + 64;
+    if (cap >= (1ULL << 32)) cap = nKept * 2 + 64;   // (table_slot() addresses 2^32 buckets per table)
+    return cap;
+  }
   bool allocate(uint64_t nKept, bool clear = true) {
-    capacity = nKept * 2 + 64;  // load factor <= 0.5
+    capacity = capacity_for(nKept);
     if (capacity >= (1ULL << 32)) return false;   // table_slot() addresses 2^32 buckets (137 GB) per table
     right = (Bucket*)malloc(capacity * sizeof(Bucket));
     left = (Bucket*)malloc(capacity * sizeof(Bucket));

@@ -32,7 +32,7 @@ __global__ void k_chase(const uint4* __restrict__ buf, uint64_t nslots, int step
 }
 int main() {
   uint64_t* sink; CK(hipMalloc(&sink, 8));
-  const double gbs[] = {0.0625, 0.25, 1, 4, 16, 64, 160};
+  const double gbs[] = {0.0625, 0.25, 1, 2, 3.5, 7, 14, 32, 64, 160};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (double gb : gbs) {
     const uint64_t bytes = (uint64_t)(gb * (1ull << 30));
