@@ -1363,7 +1363,7 @@ struct SeedExt { int lenRefExt, lenHistExt, posOnRef, score; bool stop; int extR
 // far, not by every extension.
 // MODE 0: the band fits one diagonal per lane (x up to 31: two thirds of all calls, and the instance the hot path's
 // registers and instruction cache see); 1: phases of one, two and four diagonals per lane (up to 255 diagonals);
-// 2: WIDE, with an eight-wide phase behind them (up to 511)
+// 2: WIDE, with an eight-wide and a sixteen-wide phase behind them (up to 1023 diagonals: x to 511)
 // LEAF: the instance the path search calls for its own Trails — it makes no call (what would need one, the anti-diagonal
 // sweep or a score by alignment, is reported as `fallback` and the caller asks the general function), so it saves and
 // restores nothing; and it takes the two anchors for equal, which they are by construction there (a Trail starts with
@@ -1407,8 +1407,12 @@ TALC_D SeedExt seed_and_extension_body(const uint8_t* ref, int refLen, const uin
           ph.fromLevel = 63; ph.toLevel = 127;
           rc = wave_xdrop_wfa<4>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
           if (rc == 2) {
-            ph.fromLevel = 127; ph.toLevel = -1;
+            ph.fromLevel = 127; ph.toLevel = (ndiagonals <= 511) ? -1 : 255;
             rc = wave_xdrop_wfa<8>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+            if (rc == 2) {   // x beyond 255 (a Trail of a thousand steps and more: a start anchor deep inside a long solid region)
+              ph.fromLevel = 255; ph.toLevel = -1;
+              rc = wave_xdrop_wfa<16>(seq2 + S, qlen, seq1 + S, dlen, xdrop, stage, STAGE, extCols, extRows, extScore, ncells, &ph);
+            }
           }
         }
       }
@@ -1495,7 +1499,7 @@ TALC_DN SeedExt seed_and_extension(const uint8_t* ref, int refLen, const uint8_t
     const int qlen = min(rl, cl) - S, dlen = max(rl, cl) - S;
     if (qlen > 0 && dlen > 0) {
       const int nd = min(x, qlen) + min(x, dlen) + 1;
-      if (nd > 255 && nd <= 511) [[clang::musttail]] return seed_and_extension_wide(ref, refLen, cand, candLen, xdrop, withScore);
+      if (nd > 255 && nd <= 1023) [[clang::musttail]] return seed_and_extension_wide(ref, refLen, cand, candLen, xdrop, withScore);
       if (nd > 63 && nd <= 255) [[clang::musttail]] return seed_and_extension_mid(ref, refLen, cand, candLen, xdrop, withScore);
     }
   }

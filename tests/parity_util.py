@@ -90,8 +90,12 @@ def seqs_of(buf, offs):
 
 def compare_correction(pair, bases, offs, nthreads=8, verbose=True):
     """Run both sides; returns the list of read indices that differ (sequence or status)."""
+    import time
+    t0 = time.time()
     o_out, o_off, o_st = pair.otab.correct_batch(bases, offs, nthreads=nthreads)
+    t1 = time.time()
     g_out, g_off, g_st = pair.ctx.correct(bases, offs)
+    pair.last_times = (t1 - t0, time.time() - t1)   # (oracle seconds, HIP path seconds incl. transfers)
     so, sg = seqs_of(o_out, o_off), seqs_of(g_out, g_off)
     bad = [i for i in range(len(so)) if so[i] != sg[i] or int(o_st[i]) != int(g_st[i])]
     if verbose:

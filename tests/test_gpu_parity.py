@@ -303,6 +303,41 @@ def test_device_seed_and_extension_matches_oracle(gpu_pair):
                 (n, len(cand), xdrop, direction)
 
 
+def test_device_seed_and_extension_beyond_x_255(gpu_pair):
+    """x-drops of 256 .. 511 (a Trail of a thousand steps and more, scored every CHECK_INTERVAL steps with an x that grows
+    by 2 per scoring: Explorer.cpp:713): the sixteen-diagonals-per-lane phase of the wavefront form, against the oracle's
+    anti-diagonal restatement.  Sequences as such a search has them: a nearly clean query of 300 - 1300 bases against a
+    database at least as long; beyond 511, and segments the LDS stage does not hold, the anti-diagonal sweep answers."""
+    import ctypes as C
+    rnd = random.Random(44)
+    L = O.lib()
+    ctx = gpu_pair.ctx
+    for it in range(36):
+        n = rnd.choice([400, 700, 1000, 1300, 1700])
+        ref = [rnd.choice("ACGT") for _ in range(n)]
+        cand = list(ref[: rnd.randint(300, min(n, 1300))])
+        for _ in range(rnd.choice([0, 1, 3, 10, 40])):
+            p = rnd.randrange(len(cand))
+            x = rnd.random()
+            if x < 0.4:
+                cand[p] = rnd.choice("ACGT")
+            elif x < 0.7:
+                cand.insert(p, rnd.choice("ACGT"))
+            elif len(cand) > 25:
+                del cand[p]
+        ref, cand = "".join(ref), "".join(cand)
+        xdrop = rnd.randint(256, 511) if it % 6 else rnd.randint(512, 700)
+        for direction in (0, 1):
+            out = np.zeros(3, dtype=np.int64)
+            stop = C.c_int32()
+            sc = L.orc_seed_and_extension(ref.encode(), cand.encode(), xdrop, direction, 21, out.ctypes.data, C.byref(stop))
+            a, b = (ref, cand) if direction else (ref[::-1], cand[::-1])
+            got = ctx.test_dp(1, a, b, xdrop, direction)
+            assert got[5] == 0
+            assert (got[0], got[1], got[2], got[3], got[4]) == (int(out[0]), int(out[1]), int(out[2]), int(sc), stop.value), \
+                (n, len(cand), xdrop, direction)
+
+
 def test_device_multi_xdrop_run_equals_the_single_runs(gpu_pair):
     """findStopPosition asks for x, x-1, x-2, ...: seed_and_extension_multi takes all of [0, x] from one wavefront run.
     On the device, every x of that run against the single-x routine (itself pinned to the oracle above): similar and

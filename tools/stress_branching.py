@@ -45,7 +45,7 @@ def main():
             bases, offs = half_corrected(pair, bases, offs, err_clean, kw["seed"])
         bad, (so, ost), (sg, gst) = PU.compare_correction(pair, bases, offs, nthreads=16, verbose=False)
         print(c, "k", kw["k"], "reads", len(so), "status", np.bincount(ost, minlength=4).tolist(), "mismatches", len(bad), bad[:6],
-              "%.1fs" % (time.time() - t0), "lib", os.environ.get("TALC_LIB", "default"), flush=True)
+              "%.1fs" % (time.time() - t0), "(oracle %.1fs on 16 threads, HIP path %.1fs)" % pair.last_times, "lib", os.environ.get("TALC_LIB", "default"), flush=True)
         if bad and os.environ.get("STRESS_TRACE"):
             print("  first trace difference", PU.first_trace_diff(pair, bases, offs, bad[0]))
         bad_total += len(bad)
