@@ -721,6 +721,7 @@ struct Wv {
   const uint32_t* headCov;         // the current read's kHeadCov dense counts
   uint8_t* refBuf;                 // the scratch buffer a search's reference is assembled in (ref points there, or into the read)
   uint32_t noForkStep;             // TALC_NO_FORKSTEP=1 (k_search flags bit 1): forks go through the generic step (A/B switch)
+  uint32_t childrenByLane;         // 0 with TALC_CHILDREN_SEQ=1 (flags bit 2): the generic step makes its children one at a time
 };
 
 enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
@@ -1991,6 +1992,151 @@ TALC_DNC bool record_bridge_at_aim(int nNew_, int hit_, int len_, uint64_t km2, 
   return true;
 }
 
+// ---- the children of one group of up to 64 Trails, one child per LANE (bridge searches)
+// oneMoreStep (Explorer.cpp:546-612) makes the children Trail by Trail, successor by successor, and everything it does
+// per child — the record, the base, checkAims, ThinkIveAlreadyGotThere's filter — is independent of every other child
+// except for where the child lands in the new set (Trail-major, A < C < G < T) and for the few that need the whole wave
+// (a copy for a child that does not inherit its parent's buffer; recordBridge for one that stands on an aim; the exact
+// window search for one whose k-mer the filter has seen).  So: the parents' lanes count their followed successors, a
+// prefix sum gives every child its place, the children's lanes take over — parent's record, k-mer, distance term
+// (make_child's expression), buffer, base, record into the new set at its PROVISIONAL place, aims, filter — and only the
+// few special ones are then taken one at a time, in the children's order, by the very functions the sequential form
+// uses (record_bridge_at_aim, is_cycle_exact); children that end there (:579-587) are closed up at the end.  A branching
+// graph's steps carry 5 children on average: their per-child instructions (~ 2500 wave-cycles each) become per-step
+// ones.  Returns false (nothing changed) when the group does not fit the form — more than 64 children, no room for
+// them in the new set — and the caller takes the sequential form.
+TALC_DN int bridge_children_by_lane(int tags_, uint32_t nc0, uint32_t nc1, uint32_t nc2, uint32_t nc3, int base_, int cnt_, int len_, int nNew_) {
+  // (a real call: the arguments are the lanes' tags and counts, everything else is scalar; returns the new set's size, or
+  //  -1 when the group does not fit the form)
+  StepTags mine; mine.tags = tags_; mine.nc[0] = nc0; mine.nc[1] = nc1; mine.nc[2] = nc2; mine.nc[3] = nc3;
+  const int base = uni(base_), cnt = uni(cnt_), len = uni(len_);
+  int nNew = uni(nNew_);
+  const int l = lane_id();
+  const int ib = X.ia ^ 1;
+  const int tl = base + l;
+  const bool valid = l < cnt;
+  int fm = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int tag = (int)(int8_t)((mine.tags >> (8 * i)) & 0xff); if (valid && tag != TAG_NONE && tag != TAG_UNEXPECTED) fm |= 1 << i; }
+  const int nF = __builtin_popcount((unsigned)fm);
+  int incl = nF;
+  TALC_WAVE_REDUCE(incl, talc_add_i32, 0);   // (the reduction's steps are an inclusive scan over the lanes)
+  const int excl = incl - nF;
+  const int nC = __builtin_amdgcn_readlane(incl, 63);
+  if (nC > 64 || nNew + nC > TCAP || (uint32_t)(len + 1) > X.C.seqCap) return -1;
+  {   // a Trail without a followed successor just ends
+    unsigned long long m = ballot64(valid && nF == 0);
+    while (m != 0ull) { const int t = base + (int)__builtin_ctzll(m); m &= m - 1ull; pool_free(tr_buf(X.ia, t)); }
+  }
+  if (nC == 0) return nNew;
+  uint32_t TALC_AS3* const desc = (uint32_t TALC_AS3*)g_dp;            // [64] parent | base << 9 | inherits << 11
+  uint32_t TALC_AS3* const dcnt = desc + 64;                            // [64] the successor's count
+  uint32_t TALC_AS3* const fresh = desc + 128;                          // [64] buffers handed out in this step
+  if (fm != 0) {
+    const int lastI = 31 - __builtin_clz((unsigned)fm);                 // the last followed successor inherits the buffer
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((fm >> i) & 1) {
+        desc[excl + r] = (uint32_t)tl | ((uint32_t)i << 9) | ((i == lastI) ? (1u << 11) : 0u);
+        dcnt[excl + r] = mine.nc[i];
+        ++r;
+      }
+    }
+  }
+  LSYNC();
+  const bool has = l < nC;
+  const uint32_t d = has ? desc[l] : 0u;
+  const int t = (int)(d & 511u), bI = (int)((d >> 9) & 3u);
+  const bool inherit = ((d >> 11) & 1u) != 0u;
+  const uint32_t count = has ? dcnt[l] : 1u;
+  const uint32_t K = X.P.K;
+  const uint64_t kmask = (1ULL << (2 * K)) - 1;
+  TrailRec ch = TrailRec();
+  uint32_t pbuf = 0;
+  if (has) {
+    const TrailRec p = tr_get(X.ia, t);
+    pbuf = p.buf;
+    if (X.dirRight) { ch.kmer = ((p.kmer << 2) | (uint64_t)bI) & kmask; ch.nmask = p.nmask >> 1; }
+    else { ch.kmer = ((uint64_t)bI << (2 * (K - 1))) | (p.kmer >> 2); ch.nmask = (p.nmask << 1) & ((1ULL << K) - 1); }
+    ch.cnt = count; ch.score = p.score; ch.fail = p.fail;
+    ch.dist = p.dist + fabs((double)p.cnt - (double)count) / sqrt((double)p.cnt);   // (tagNextNodes' distance term, as make_child)
+    ch.lanc = p.lanc; ch.ranc = p.ranc; ch.buf = p.buf;
+  }
+  // buffers for the children that do not inherit one
+  const unsigned long long freshM = ballot64(has && !inherit);
+  const int nFresh = (int)__popcll(freshM);
+  if (nFresh != 0) {
+    for (int k = 0; k < nFresh; ++k) { const uint32_t id = (uint32_t)pool_alloc(); if (l == 0) fresh[k] = id; }
+    if (l == 0) g_keep.owner = 0u;   // (buffers change hands: a kept wavefront may be about former contents)
+    WSYNC();                         // (also: bases appended by single lanes in earlier steps become visible to the copying lanes)
+    const unsigned long long below = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    if (has && !inherit) ch.buf = fresh[(int)__popcll(freshM & below)];
+    unsigned long long m = freshM;
+    while (m != 0ull) {
+      const int f = (int)__builtin_ctzll(m); m &= m - 1ull;
+      copy_trail((uint32_t)lane_get((int)ch.buf, f), (uint32_t)lane_get((int)pbuf, f), len, true);
+    }
+  }
+  const int slot = nNew + l;                                            // provisional place in the new set
+  if (has) {
+    ((gu8)X.seqPool)[(uint64_t)ch.buf * X.C.seqCap + (uint32_t)len] = (uint8_t)bI;
+    tr_put(ib, slot, ch);
+  }
+  WSYNC();
+  // checkAims (Trail.cpp:273-285): the first aim whose k-mer is the child's tip
+  int hit = -1;
+  {
+    const AnchorRec* aims = X.dirRight ? X.ancR : X.ancL;
+    const int nAims = X.dirRight ? X.nAncR : X.nAncL;
+    const int nl = min(nAims, AIMS_LDS);
+    for (int a = 0; a < nl; ++a) if (has && hit < 0 && g_aimK[a] == ch.kmer && g_aimN[a] == ch.nmask) hit = a;
+    for (int a = AIMS_LDS; a < nAims; ++a) { const AnchorRec ar = aims[a]; if (has && hit < 0 && ar.kmer == ch.kmer && ar.nmask == ch.nmask) hit = a; }
+  }
+  // ThinkIveAlreadyGotThere's filter (Trail.cpp:289-302)
+  uint32_t hv = 0;
+  bool maybe = false;
+  if (has && hit < 0) maybe = bloom_query(ch.kmer, ch.nmask, hv) && (len > (int)K);
+#ifdef TALC_PROF
+  { const int q = (int)__popcll(ballot64(has && hit < 0)), x = (int)__popcll(ballot64(maybe)); if (l == 0) { g_prof[PF_CYQ] += (uint32_t)q; g_prof[PF_CYX] += (uint32_t)x; } }
+#endif
+  // the few that need the whole wave, in the children's order
+  unsigned long long sp = ballot64(has && (hit >= 0 || maybe)), popM = 0ull;
+  while (sp != 0ull) {
+    const int f = (int)__builtin_ctzll(sp); sp &= sp - 1ull;
+    const int hitF = lane_get(hit, f);
+    if (hitF >= 0) {
+      const uint64_t kmF = ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(ch.kmer >> 32), f) << 32) | (uint32_t)lane_get((int)(uint32_t)ch.kmer, f);
+      const uint64_t nmF = ((uint64_t)(uint32_t)lane_get((int)(uint32_t)(ch.nmask >> 32), f) << 32) | (uint32_t)lane_get((int)(uint32_t)ch.nmask, f);
+      if (!uni((int)record_bridge_at_aim(nNew + f, hitF, len, kmF, nmF))) popM |= 1ull << f;   // :579-582 pop_back
+    } else {
+      const bool cyc = uni((int)is_cycle_exact(lane_get(t, f), nNew + f, len)) != 0;
+#ifdef TALC_PROF
+      if (l == 0 && cyc) g_prof[PF_CYHIT] += 1;
+#endif
+      if (cyc) { pool_free((uint32_t)lane_get((int)ch.buf, f)); popM |= 1ull << f; }          // :586-587 pop_back
+    }
+  }
+  const bool surv = has && (((popM >> l) & 1ull) == 0ull);
+  // the survivors' k-mers enter the filter now (a child on an aim was entered by recordBridge's path already)
+  if (surv && hit < 0) {
+    atomicOr(&g_bloom[hv >> 25], (1ull << ((hv >> 19) & 63u)) | (1ull << ((hv >> 13) & 63u)));
+    const uint32_t wm = X.wideMask;
+    if (wm != 0u) wide_or(X.wideBloom + wide_word(hv, wm), wide_bits(hv));
+  }
+  const unsigned long long survM = ballot64(surv);
+  if (popM != 0ull) {   // close the gaps (a record may have changed where it stands: recordBridge sets the anchor reached)
+    TrailRec r = TrailRec();
+    if (surv) r = tr_get(ib, slot);
+    WSYNC();
+    const unsigned long long below = (l == 0) ? 0ull : (~0ull >> (64 - l));
+    if (surv) tr_put(ib, nNew + (int)__popcll(survM & below), r);
+  }
+  nNew += (int)__popcll(survM);
+  WSYNC();
+  return nNew;
+}
+
 // (inlined at its one call site: as a real call — tried again in round 3, after step_edge had become one — the 4.3 M
 //  generic bridge steps of a config-2 launch pay for a prologue each: 40.7 -> 42.5 ms)
 TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
@@ -2003,6 +2149,7 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
   int nNew = 0;
   uint32_t pend = 0; int nPend = 0;   // this step's children, to be entered into the filter (bloom_flush)
   const bool complexIn = ((uint32_t)nCur > P.MAXB);
+  const bool byLane = uni((int)X.childrenByLane) != 0;
   for (int base = 0; base < nCur; base += 64) {
     const int tl = base + l;
     PROF_BEGIN();
@@ -2010,6 +2157,12 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
     PROF_END(PF_PROBE);
     const int cnt = min(64, nCur - base);
     X.steps += (unsigned long long)cnt;
+    if (byLane) {
+      PROF_BEGIN();
+      const int nn = uni(bridge_children_by_lane(mine.tags, mine.nc[0], mine.nc[1], mine.nc[2], mine.nc[3], base, cnt, len, nNew));
+      PROF_END(PF_CHILD);
+      if (nn >= 0) { nNew = nn; continue; }
+    }
     for (int tt = 0; tt < cnt; ++tt) {
       const int t = base + tt;
       const int tags = lane_get(mine.tags, tt);
@@ -3168,6 +3321,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.rowPool = (flags & 1u) ? nullptr : (int*)(slot + C.o_rowPool); X.rowStride = 0; X.rowAvail = 0;   // (flags bit 0: TALC_NO_ROWS)
   X.launchStamp = launchStamp;
   X.noForkStep = (flags >> 1) & 1u;
+  X.childrenByLane = ((flags >> 2) & 1u) ^ 1u;
   X.searchNo = 16u;   // (stamps below 16 << 12 could be matrix values)
   {
     uint8_t* g = slot + C.o_gard;

@@ -38,6 +38,7 @@ TALC_D int wave_max_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 TALC_D int talc_or_i32(int a, int b) { return a | b; }
+TALC_D int talc_add_i32(int a, int b) { return a + b; }
 TALC_D unsigned wave_or_u32(unsigned v) {
   int w = (int)v;
   TALC_WAVE_REDUCE(w, talc_or_i32, 0);
