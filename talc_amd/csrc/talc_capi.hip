@@ -266,15 +266,10 @@ int talc_table_from_arrays(const uint64_t* kmers, const uint32_t* counts, uint64
 }
 
 // the table built on `device` (talc_kernels_build.h); the image stays there (staged) until talc_table_upload adopts it
-int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts, uint64_t n, const talc_params* p, int device,
-                                  talc_table** out) {
-  int rc = check_params(p);
-  if (rc) return rc;
-  if (!out || (n && (!kmers || !counts))) return fail(TALC_ERR_INVALID, "null argument");
-  if (n >= 0xFFFFFFFEull) return fail(TALC_ERR_INVALID, "the device builder takes fewer than 2^32-2 entries");
-  uint64_t kept = 0;
-#pragma omp parallel for reduction(+ : kept)
-  for (long i = 0; i < (long)n; ++i) kept += counts[i] >= p->min_count ? 1 : 0;
+// the device builder's core: n dump lines as device arrays dK / dC (line i of the dump at index i; the kernels drop the
+// lines below MIN_COUNT themselves), `kept` = how many reach MIN_COUNT (sizes the tables).  Takes ownership of dK / dC.
+static int build_table_from_device_arrays(uint64_t* dK, uint32_t* dC, uint64_t n, uint64_t kept, const talc_params* p, int device,
+                                          talc_table** out, double h2d_seconds, double h2d_megabytes) {
   talc_table* t = new talc_table();
   t->h.p = *p;
   {   // (sparser than load 0.5 when the device has the room: HostTable::capacity_for)
@@ -283,27 +278,23 @@ int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts,
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) devBytes = (uint64_t)prop.totalGlobalMem;
     t->h.capacity = HostTable::capacity_for(kept, devBytes);
   }
-  if (t->h.capacity >= (1ULL << 32)) { delete t; return fail(TALC_ERR_NOMEM, "table of %llu k-mers exceeds 2^32 buckets", (unsigned long long)kept); }
+  uint32_t *dSR = nullptr, *dSL = nullptr;
+  unsigned long long* dStats = nullptr;
+  Bucket *dR = nullptr, *dL = nullptr;
+  auto cleanup = [&]() { hipFree(dK); hipFree(dC); hipFree(dSR); hipFree(dSL); hipFree(dStats); };
+  if (t->h.capacity >= (1ULL << 32)) { cleanup(); delete t; return fail(TALC_ERR_NOMEM, "table of %llu k-mers exceeds 2^32 buckets", (unsigned long long)kept); }
   t->hostValid = false;
   const uint64_t cap = t->h.capacity, bytes = cap * sizeof(Bucket);
-  Bucket *dR = nullptr, *dL = nullptr;
-  uint64_t* dK = nullptr; uint32_t *dC = nullptr, *dSR = nullptr, *dSL = nullptr;
-  unsigned long long* dStats = nullptr;
-  auto cleanup = [&]() { hipFree(dK); hipFree(dC); hipFree(dSR); hipFree(dSL); hipFree(dStats); };
 #define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); hipFree(dR); hipFree(dL); delete t; return fail(TALC_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
   const bool timing = getenv("TALC_TIMING") != nullptr;
   auto tnow = []() { return std::chrono::steady_clock::now(); };
   auto tsec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-  const auto td0 = tnow();
-  BCHK(hipSetDevice(device));
-  BCHK(hipFree(nullptr));   // (the runtime's own start-up, apart from this call's work in the timing below)
   const auto td1 = tnow();
+  BCHK(hipSetDevice(device));
   BCHK(hipMalloc((void**)&dR, bytes)); BCHK(hipMalloc((void**)&dL, bytes));
-  BCHK(hipMalloc((void**)&dK, std::max<uint64_t>(n, 1) * 8)); BCHK(hipMalloc((void**)&dC, std::max<uint64_t>(n, 1) * 4));
   BCHK(hipMalloc((void**)&dSR, std::max<uint64_t>(n, 1) * 4)); BCHK(hipMalloc((void**)&dSL, std::max<uint64_t>(n, 1) * 4));
   BCHK(hipMalloc((void**)&dStats, 3 * 8));
   BCHK(hipMemset(dR, 0xFF, bytes)); BCHK(hipMemset(dL, 0xFF, bytes)); BCHK(hipMemset(dStats, 0, 3 * 8));
-  if (n) { BCHK(hipMemcpy(dK, kmers, n * 8, hipMemcpyHostToDevice)); BCHK(hipMemcpy(dC, counts, n * 4, hipMemcpyHostToDevice)); }
   BCHK(hipDeviceSynchronize());
   const auto td2 = tnow();
   if (n) {
@@ -320,12 +311,118 @@ int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts,
 #undef BCHK
   const auto td3 = tnow();
   cleanup();
-  if (timing) fprintf(stderr, "[talc-lib] device build: runtime start-up %.3f s, allocations + clears + %.0f MB of H2D %.3f s, kernels %.3f s, frees %.3f s\n",
-                      tsec(td0, td1), (double)n * 12 / 1e6, tsec(td1, td2), tsec(td2, td3), tsec(td3, tnow()));
+  if (timing) fprintf(stderr, "[talc-lib] device build: %.0f MB to the device %.3f s, table allocations + clears %.3f s, kernels %.3f s, frees %.3f s\n",
+                      h2d_megabytes, h2d_seconds, tsec(td1, td2), tsec(td2, td3), tsec(td3, tnow()));
   t->stagedDev = device; t->stR = dR; t->stL = dL;
   t->h.nkmers = st[0]; t->h.nbuckets_right = st[1]; t->h.nbuckets_left = st[2];
   *out = t;
   return TALC_OK;
+}
+
+int talc_table_from_arrays_device(const uint64_t* kmers, const uint32_t* counts, uint64_t n, const talc_params* p, int device,
+                                  talc_table** out) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!out || (n && (!kmers || !counts))) return fail(TALC_ERR_INVALID, "null argument");
+  if (n >= 0xFFFFFFFEull) return fail(TALC_ERR_INVALID, "the device builder takes fewer than 2^32-2 entries");
+  uint64_t kept = 0;
+#pragma omp parallel for reduction(+ : kept)
+  for (long i = 0; i < (long)n; ++i) kept += counts[i] >= p->min_count ? 1 : 0;
+  uint64_t* dK = nullptr; uint32_t* dC = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipFree(nullptr);   // (the runtime's own start-up)
+  if (e == hipSuccess) e = hipMalloc((void**)&dK, std::max<uint64_t>(n, 1) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dC, std::max<uint64_t>(n, 1) * 4);
+  if (e == hipSuccess && n) e = hipMemcpy(dK, kmers, n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess && n) e = hipMemcpy(dC, counts, n * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(dK); hipFree(dC); return fail(TALC_ERR_DEVICE, "copying the dump's arrays to the device: %s", hipGetErrorString(e)); }
+  const double h2d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return build_table_from_device_arrays(dK, dC, n, kept, p, device, out, h2d, (double)n * 12 / 1e6);
+}
+
+// The text dump parsed ON the device (talc_kernels_build.h): the file's bytes are read by a few host threads into
+// page-locked buffers and copied as they are; two kernels make the builder's arrays.  Returns TALC_OK with *out set, or
+// a positive value when the file is not for this route (too small to matter, a line that is not canonical, no memory):
+// the caller then parses on the host, as before.
+static int table_from_text_on_device(const char* path, const talc_params* p, int device, talc_table** out, DumpStats& ds) {
+  struct stat sb;
+  if (stat(path, &sb) != 0) return fail(TALC_ERR_IO, "cannot open %s", path);
+  const uint64_t size = (uint64_t)sb.st_size;
+  if (size < (8u << 20) || getenv("TALC_HOST_PARSE")) return 1;
+  {   // a Jellyfish 2 count file goes the host's way (talc_jf.h)
+    char head[64] = {0};
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(TALC_ERR_IO, "cannot open %s", path);
+    const size_t got = fread(head, 1, sizeof head, f);
+    fclose(f);
+    if (jfLooksLike(head, got)) return 1;
+  }
+  const bool timing = getenv("TALC_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto secs = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+  if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) return fail(TALC_ERR_DEVICE, "device %d cannot be used", device);
+  uint8_t* dText = nullptr;
+  if (hipMalloc((void**)&dText, size + 64) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  // ---- the file's bytes to the device: reader threads, each with its own descriptor, page-locked buffer and stream
+  const uint64_t CH = 32ull << 20;
+  const uint64_t nch = (size + CH - 1) / CH;
+  const int T = (int)std::min<uint64_t>(nch, 8);
+  std::atomic<uint64_t> next{0};
+  std::atomic<int> err{0};
+#pragma omp parallel num_threads(T)
+  {
+    int fd = open(path, O_RDONLY);
+    void* pin = nullptr;
+    hipStream_t st = nullptr;
+    bool ok = fd >= 0 && hipSetDevice(device) == hipSuccess && hipHostMalloc(&pin, CH) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    while (ok && !err.load()) {
+      const uint64_t i = next.fetch_add(1);
+      if (i >= nch) break;
+      const uint64_t off = i * CH, len = std::min<uint64_t>(CH, size - off);
+      uint64_t got = 0;
+      while (got < len) { const ssize_t r = pread(fd, (char*)pin + got, len - got, (off_t)(off + got)); if (r <= 0) { ok = false; break; } got += (uint64_t)r; }
+      if (!ok) break;
+      if (hipMemcpyAsync(dText + off, pin, len, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) ok = false;
+    }
+    if (!ok) err.store(1);
+    if (st) hipStreamDestroy(st);
+    if (pin) hipHostFree(pin);
+    if (fd >= 0) close(fd);
+  }
+  if (err.load()) { hipFree(dText); (void)hipGetLastError(); return 1; }
+  const double tUp = secs(t0);
+  // ---- lines per tile, the tiles' first line numbers, the lines themselves
+  const auto t1 = std::chrono::steady_clock::now();
+  const uint64_t ntiles = (size + kParseTile - 1) / kParseTile;
+  uint32_t* dCount = nullptr; uint64_t* dFirst = nullptr; ParseStats* dPS = nullptr;
+  uint64_t* dK = nullptr; uint32_t* dC = nullptr;
+  auto drop = [&]() { hipFree(dText); hipFree(dCount); hipFree(dFirst); hipFree(dPS); hipFree(dK); hipFree(dC); (void)hipGetLastError(); };
+  if (ntiles >= (1ull << 31) || hipMalloc((void**)&dCount, ntiles * 4) != hipSuccess || hipMalloc((void**)&dFirst, ntiles * 8) != hipSuccess ||
+      hipMalloc((void**)&dPS, sizeof(ParseStats)) != hipSuccess || hipMemset(dPS, 0, sizeof(ParseStats)) != hipSuccess) { drop(); return 1; }
+  hipLaunchKernelGGL(k_parse_count, dim3((unsigned)ntiles), dim3(kParseThreads), 0, 0, dText, size, dCount);
+  std::vector<uint32_t> hCount(ntiles);
+  if (hipMemcpy(hCount.data(), dCount, ntiles * 4, hipMemcpyDeviceToHost) != hipSuccess) { drop(); return 1; }
+  std::vector<uint64_t> hFirst(ntiles);
+  uint64_t nlines = 0;
+  for (uint64_t i = 0; i < ntiles; ++i) { hFirst[i] = nlines; nlines += hCount[i]; }
+  if (nlines == 0 || nlines >= 0xFFFFFFFEull) { drop(); return 1; }
+  if (hipMemcpy(dFirst, hFirst.data(), ntiles * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc((void**)&dK, nlines * 8) != hipSuccess || hipMalloc((void**)&dC, nlines * 4) != hipSuccess) { drop(); return 1; }
+  hipLaunchKernelGGL(k_parse_lines, dim3((unsigned)ntiles), dim3(kParseThreads), 0, 0, dText, size, dFirst, p->k, p->min_count, dK, dC, dPS);
+  ParseStats ps;
+  if (hipGetLastError() != hipSuccess || hipMemcpy(&ps, dPS, sizeof ps, hipMemcpyDeviceToHost) != hipSuccess) { drop(); return 1; }
+  hipFree(dText); hipFree(dCount); hipFree(dFirst); hipFree(dPS);
+  dText = nullptr; dCount = nullptr; dFirst = nullptr; dPS = nullptr;
+  if (ps.flags != 0) {   // a line the device parser does not take: the host's tokeniser decides what every line means
+    hipFree(dK); hipFree(dC);
+    if (timing) fprintf(stderr, "[talc-lib] the dump has lines that are not 'KMER count': parsing on the host\n");
+    return 1;
+  }
+  if (timing) fprintf(stderr, "[talc-lib] dump parsed on the device: %.0f MB of text to the device in %.3f s (%d reader threads), %llu lines parsed in %.3f s\n",
+                      (double)size / 1e6, tUp, T, (unsigned long long)nlines, secs(t1));
+  ds.nread += (int64_t)nlines; ds.nkept += (int64_t)ps.kept;
+  return build_table_from_device_arrays(dK, dC, nlines, ps.kept, p, device, out, 0.0, 0.0);
 }
 
 // Junction colouring (Jellyfish.cpp:273-290) on the staged device image: last line wins, both strands.
@@ -375,18 +472,27 @@ static int table_build_impl(const char* dump_path, const char* junction_path, co
   std::string why;
   const bool timing = getenv("TALC_TIMING") != nullptr;   // (diagnostic: where a table build's wall time goes, on stderr)
   const auto tb0 = std::chrono::steady_clock::now();
-  if (!parseDumpFile(dump_path, p->k, p->min_count, true, kmers, &counts, nullptr, ds, &why))
-    return why.empty() ? fail(TALC_ERR_IO, "cannot open %s", dump_path) : fail(TALC_ERR_INVALID, "%s", why.c_str());
-  const auto tb1 = std::chrono::steady_clock::now();
   talc_table* t = nullptr;
-  rc = (device >= 0) ? talc_table_from_arrays_device(kmers.data(), counts.data(), kmers.size(), p, device, &t)
-                     : talc_table_from_arrays(kmers.data(), counts.data(), kmers.size(), p, &t);
-  if (timing) {
-    const auto tb2 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[talc-lib] dump parse %.3f s (%llu lines), table build on %s %.3f s\n", std::chrono::duration<double>(tb1 - tb0).count(),
-            (unsigned long long)ds.nread, device >= 0 ? "the device (incl. its first HIP call)" : "the host", std::chrono::duration<double>(tb2 - tb1).count());
+  int viaDevice = 1;   // > 0: not taken
+  if (device >= 0) {
+    viaDevice = table_from_text_on_device(dump_path, p, device, &t, ds);
+    if (viaDevice < 0) return viaDevice;
+    if (viaDevice == 0 && timing)
+      fprintf(stderr, "[talc-lib] dump to table on the device %.3f s (%llu lines)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count(), (unsigned long long)ds.nread);
   }
-  if (rc) return rc;
+  if (viaDevice > 0) {
+    if (!parseDumpFile(dump_path, p->k, p->min_count, true, kmers, &counts, nullptr, ds, &why))
+      return why.empty() ? fail(TALC_ERR_IO, "cannot open %s", dump_path) : fail(TALC_ERR_INVALID, "%s", why.c_str());
+    const auto tb1 = std::chrono::steady_clock::now();
+    rc = (device >= 0) ? talc_table_from_arrays_device(kmers.data(), counts.data(), kmers.size(), p, device, &t)
+                       : talc_table_from_arrays(kmers.data(), counts.data(), kmers.size(), p, &t);
+    if (timing) {
+      const auto tb2 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[talc-lib] dump parse %.3f s (%llu lines), table build on %s %.3f s\n", std::chrono::duration<double>(tb1 - tb0).count(),
+              (unsigned long long)ds.nread, device >= 0 ? "the device (incl. its first HIP call)" : "the host", std::chrono::duration<double>(tb2 - tb1).count());
+    }
+    if (rc) return rc;
+  }
   std::vector<uint64_t>().swap(kmers);
   std::vector<uint32_t>().swap(counts);
   if (junction_path && junction_path[0]) {  // Jellyfish.cpp:273-290

@@ -265,4 +265,89 @@ __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __r
   out[1] = v4u32{lv[4] | (lv[5] << 16), lv[6] | (lv[7] << 16), lv[8] | (lv[9] << 16), lv[10] | (lv[11] << 16)};
 }
 
+
+// ==================================================================== the text dump parsed on the device
+// `jellyfish dump -c` writes one canonical line per k-mer — K letters of ACGT, one blank, one to nine digits, a newline —
+// and a 500 M-line dump is 19 GB of them: parsed on the host (128 threads over the mapped file) that took 6.6 s of a
+// 12.5 s run, most of it page faults and vector growth, not parsing.  Here the file's bytes go to the GPU as they are
+// (several reader threads, page-locked staging buffers) and two kernels turn them into the builder's arrays, line i of the
+// file at index i (Jellyfish.cpp:251-269: the first line of a k-mer wins, so the line number is what the builder's
+// atomicMin compares): k_parse_count counts the lines that start in each 16 KB tile, the host turns the counts into the
+// tiles' first line numbers, k_parse_lines parses every line from its start.  Any line that is not canonical (other white
+// space, another length, a letter outside ACGT, no count, a count of ten digits, no newline at the end of the file) raises
+// a flag and the whole file goes through the host's tokeniser instead, which is the one that knows what the reference
+// does with such lines; the builder kernels apply the MIN_COUNT filter themselves.
+constexpr int kParseThreads = 256, kParseSlice = 64, kParseTile = kParseThreads * kParseSlice;
+struct ParseStats { unsigned long long kept, flags; };   // flags != 0: a line the device parser does not take
+
+TALC_D bool parse_line_start(const uint8_t* __restrict__ text, uint64_t size, uint64_t p) {
+  return p < size && (p == 0 || text[p - 1] == (uint8_t)'\n');
+}
+
+__global__ void __launch_bounds__(kParseThreads)
+k_parse_count(const uint8_t* __restrict__ text, uint64_t size, uint32_t* __restrict__ tileCount) {
+  const uint64_t s0 = (uint64_t)blockIdx.x * kParseTile + (uint64_t)threadIdx.x * kParseSlice;
+  uint32_t n = 0;
+  if (s0 < size) {
+    // newline bytes of [s0 - 1, s0 + 63): a line starts after each of them
+    const uint64_t lo = s0 == 0 ? 0 : s0 - 1, hi = min(size, s0 + (uint64_t)kParseSlice) - 1;   // the last byte of the file starts nothing
+    if (s0 == 0) n = 1;
+    for (uint64_t q = lo; q < hi; ++q) n += text[q] == (uint8_t)'\n' ? 1u : 0u;
+  }
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_down((int)n, off, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_n, n);
+  __syncthreads();
+  if (threadIdx.x == 0) tileCount[blockIdx.x] = s_n;
+}
+
+__global__ void __launch_bounds__(kParseThreads)
+k_parse_lines(const uint8_t* __restrict__ text, uint64_t size, const uint64_t* __restrict__ tileFirstLine, uint32_t K, uint32_t minc,
+              uint64_t* __restrict__ kmers, uint32_t* __restrict__ counts, ParseStats* __restrict__ stats) {
+  const uint64_t s0 = (uint64_t)blockIdx.x * kParseTile + (uint64_t)threadIdx.x * kParseSlice;
+  // the line starts of this thread's slice (a line is at least K + 3 >= 21 bytes: at most four per slice)
+  uint64_t st[4];
+  uint32_t n = 0;
+  bool bad = false;
+  if (s0 < size) {
+    const uint64_t hi = min(size, s0 + (uint64_t)kParseSlice);
+    for (uint64_t q = s0; q < hi; ++q) {
+      if (parse_line_start(text, size, q)) { if (n < 4) st[n] = q; else bad = true; ++n; }
+    }
+  }
+  // rank of the thread's first line within the tile: exclusive scan over the block
+  __shared__ uint32_t s_scan[kParseThreads];
+  s_scan[threadIdx.x] = n;
+  __syncthreads();
+  for (int off = 1; off < kParseThreads; off <<= 1) {
+    const uint32_t add = (threadIdx.x >= (unsigned)off) ? s_scan[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s_scan[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint64_t line = tileFirstLine[blockIdx.x] + (s_scan[threadIdx.x] - n);
+  uint32_t kept = 0;
+  for (uint32_t j = 0; j < min(n, 4u); ++j, ++line) {
+    const uint64_t p = st[j];
+    uint64_t v = 0;
+    uint32_t cv = 0;
+    bool ok = p + K + 2 < size;
+    if (ok) {
+      for (uint32_t i = 0; i < K; ++i) { const uint8_t c = ascii_to_code(text[p + i]); ok &= c < 4; v = (v << 2) | (uint64_t)(c & 3u); }
+      ok &= text[p + K] == (uint8_t)' ' || text[p + K] == (uint8_t)'\t';
+      uint64_t d = p + K + 1;
+      int nd = 0;
+      while (d < size && (uint32_t)(text[d] - (uint8_t)'0') < 10u && nd < 9) { cv = cv * 10u + (uint32_t)(text[d] - (uint8_t)'0'); ++d; ++nd; }
+      ok &= nd > 0 && d < size && text[d] == (uint8_t)'\n';
+    }
+    if (ok) { kmers[line] = v; counts[line] = cv; kept += cv >= minc ? 1u : 0u; }
+    else bad = true;
+  }
+  if (bad) atomicOr(&stats->flags, 1ull);
+  for (int off = 32; off > 0; off >>= 1) kept += __shfl_down((int)kept, off, 64);
+  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&stats->kept, (unsigned long long)kept);
+}
+
 }  // namespace talc

@@ -463,6 +463,7 @@ int main(int argc, const char** argv) {
   auto setFailed = [&]() { std::lock_guard<std::mutex> g(failMu); if (!failed) failMsg = talc_last_error(); failed = true; };
   double readBusy = 0, writeBusy = 0;            // under rdMu / wrMu
   std::atomic<long long> deviceBusyUs{0};        // summed over the workers
+  std::atomic<long long> ctxUs{0}, createUs{0}, correctUs{0}, fetchUs{0}, unpackUs{0}, waitChunkUs{0};   // ... and its parts
   auto readChunk = [&](PinnedBuf& in) -> std::unique_ptr<Chunk> {
     std::lock_guard<std::mutex> g(rdMu);
     const auto tr0 = std::chrono::steady_clock::now();
@@ -528,10 +529,15 @@ int main(int argc, const char** argv) {
   };
   auto worker = [&](int device) {
     talc_ctx* ctx = nullptr;
-    if (device >= 0 && talc_ctx_create(table, &o.p, device, &ctx) != TALC_OK) { setFailed(); return; }
+    auto usSince = [](std::chrono::steady_clock::time_point t) { return (long long)(1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); };
+    { const auto tc0 = std::chrono::steady_clock::now();
+      if (device >= 0 && talc_ctx_create(table, &o.p, device, &ctx) != TALC_OK) { setFailed(); return; }
+      ctxUs += usSince(tc0); }
     PinnedBuf in, outb;
     while (!failed) {
+      const auto tw0 = std::chrono::steady_clock::now();
       std::unique_ptr<Chunk> c = readChunk(in);
+      waitChunkUs += usSince(tw0);
       if (!c) break;
       if (device < 0) {
         passThrough(*c, in);
@@ -542,16 +548,23 @@ int main(int argc, const char** argv) {
         const auto td0 = std::chrono::steady_clock::now();
         struct Acc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~Acc() { a += (long long)(1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } acc{deviceBusyUs, td0};
         if (talc_batch_create(ctx, in.p, c->offsets.data(), n, &b) != TALC_OK) { setFailed(); break; }
+        createUs += usSince(td0);
+        const auto tk0 = std::chrono::steady_clock::now();
         // < 0: a real HIP / argument error stops the run; TALC_WARN_READ_ERRORS (> 0) is a complete batch in which some
         // reads kept their input sequence (status TALC_READ_ERROR -> a .log line), and the run goes on
         const int crc = talc_batch_correct(ctx, b);
         if (crc < 0) { setFailed(); talc_batch_destroy(b); break; }
+        correctUs += usSince(tk0);
+        const auto tf0 = std::chrono::steady_clock::now();
         const uint64_t total = talc_batch_corrected_bytes(b);
         std::vector<uint64_t> oo(n + 1);
         if (!outb.reserve(std::max<uint64_t>(total, 1))) { setFailed(); talc_batch_destroy(b); break; }
         if (talc_batch_fetch_corrected(ctx, b, outb.p, total, oo.data(), c->status.data()) != TALC_OK) { setFailed(); talc_batch_destroy(b); break; }
         if (o.readStats) { c->stats.resize(5ull * n); if (talc_batch_fetch_read_stats(ctx, b, c->stats.data()) != TALC_OK) { setFailed(); talc_batch_destroy(b); break; } }
+        fetchUs += usSince(tf0);
+        const auto tu0 = std::chrono::steady_clock::now();
         for (uint32_t i = 0; i < n; ++i) c->out[i].assign(outb.p + oo[i], oo[i + 1] - oo[i]);
+        unpackUs += usSince(tu0);
         if (crc > 0) for (uint32_t i = 0; i < n; ++i) readErrors += c->status[i] == TALC_READ_ERROR ? 1 : 0;
         talc_batch_destroy(b);
       }
@@ -582,8 +595,10 @@ int main(int argc, const char** argv) {
           (unsigned long long)nextIndex, o.batchReads, secs(t0, t3));
   fprintf(stderr, "[talc-timing] {\"scan_s\": %.4f, \"table_parse_build_s\": %.4f, \"upload_s\": %.4f, \"correct_phase_s\": %.4f, "
                   "\"reader_busy_s\": %.4f, \"device_busy_s_sum_over_workers\": %.4f, \"writer_busy_s\": %.4f, \"total_s\": %.4f, "
+                  "\"device_parts_s\": {\"ctx_create\": %.4f, \"batch_create_h2d\": %.4f, \"correct\": %.4f, \"fetch_d2h\": %.4f, \"records_to_strings\": %.4f, \"waiting_for_reader\": %.4f}, "
                   "\"reads\": %llu, \"bases\": %llu, \"batches\": %llu, \"batch_reads\": %u, \"gpus\": %d, \"workers\": %d}\n",
           secs(t0, t1), secs(t1, t2), secs(t2, t2b), secs(t2b, t3), readBusy, (double)deviceBusyUs.load() / 1e6, writeBusy, secs(t0, t3),
+          ctxUs.load() / 1e6, createUs.load() / 1e6, correctUs.load() / 1e6, fetchUs.load() / 1e6, unpackUs.load() / 1e6, waitChunkUs.load() / 1e6,
           (unsigned long long)nReadsTotal, (unsigned long long)basesTotal, (unsigned long long)nextIndex, o.batchReads, ndev, emptyRun ? 1 : 2 * ndev);
   return 0;
 }

@@ -891,6 +891,61 @@ def test_device_built_table_matches_the_oracle_table(tmp_path):
     assert (a[0] == ec).all() and (a[1] == ej).all() and (b[0] == ec).all() and (b[1] == ej).all()
 
 
+def test_text_dump_parsed_on_the_device_equals_the_host_parser(tmp_path, capfd, monkeypatch):
+    """A dump of a size that matters goes to the GPU as text and is parsed there (talc_kernels_build.h: k_parse_count /
+    k_parse_lines): same table, same statistics as the host parser gives — duplicated lines (the first wins: the line number
+    is the order), counts below MIN_COUNT, counts of 1-9 digits, a tab as the blank; and any line that is not canonical (a
+    lower-case k-mer is canonical; two blanks, a carriage return, a trailing blank, a count of ten digits, no newline at the end are not) sends the
+    whole file through the host's tokeniser, with the same answers as before."""
+    from talc_amd.synth import Synth
+    S = Synth(target_kmers=420_000, k=21, seed=43)
+    keys, counts = S.dump_arrays()
+    rng = np.random.default_rng(5)
+    p, q = PU.both_params(k=21)
+    lines = ["%s %d" % (unpack_kmer(k, 21), int(c)) for k, c in zip(keys, counts)]
+    dup = rng.integers(0, len(keys), 4000)
+    lines += ["%s\t%d" % (unpack_kmer(keys[i], 21).lower(), int(counts[i]) + 5) for i in dup]        # later duplicates lose
+    lines = ["%s 1" % unpack_kmer(keys[i], 21) for i in dup[:300]] + lines                           # earlier ones below MIN_COUNT do not count
+    lines += ["%s 123456789" % unpack_kmer(int(rng.integers(0, 1 << 42)), 21) for _ in range(50)]   # nine digits
+    canonical = str(tmp_path / "canonical.txt")
+    with open(canonical, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    assert os.path.getsize(canonical) > (8 << 20)
+    monkeypatch.setenv("TALC_TIMING", "1")
+    capfd.readouterr()
+    td = T.Table.from_files(canonical, None, p, device=0)
+    assert "dump parsed on the device" in capfd.readouterr().err
+    monkeypatch.setenv("TALC_HOST_PARSE", "1")
+    th = T.Table.from_files(canonical, None, p, device=0)
+    assert "dump parsed on the device" not in capfd.readouterr().err
+    monkeypatch.delenv("TALC_HOST_PARSE")
+    ofile = O.OracleTable(q, O.OracleTable.FLAT)
+    ost = ofile.build_from_files(canonical, None)
+    assert len(td) == len(th) == len(ofile) and (td.build_stats == th.build_stats).all()
+    assert int(td.build_stats[0]) == int(ost[0]) and int(td.build_stats[1]) == int(ost[1])
+    qs = np.concatenate([keys, rng.integers(0, 1 << 42, 50000, dtype=np.uint64)])
+    ec, ej = ofile.lookup_packed(qs)
+    for t in (td, th):
+        c, j = t.lookup_host(qs)
+        assert (c == ec).all() and (j == ej).all()
+    # lines the device parser does not take: the host's tokeniser answers for the whole file
+    for name, extra in (("two-blanks", ["%s  7" % unpack_kmer(keys[5], 21)]), ("crlf", ["%s 7\r" % unpack_kmer(keys[8], 21)]), ("trailing-blank", ["%s 7 " % unpack_kmer(keys[6], 21)]),
+                        ("no-final-newline", None), ("ten-digits", ["%s 1234567890" % unpack_kmer(keys[7], 21)])):
+        path = str(tmp_path / (name + ".txt"))
+        with open(path, "w") as f:
+            f.write("\n".join(lines[:len(lines) // 2] + (extra or []) + lines[len(lines) // 2:]) + ("" if extra is None else "\n"))
+        capfd.readouterr()
+        tdev = T.Table.from_files(path, None, p, device=0)
+        err = capfd.readouterr().err
+        assert "dump parsed on the device" not in err and "parsing on the host" in err, name
+        oo = O.OracleTable(q, O.OracleTable.FLAT)
+        oo.build_from_files(path, None)
+        assert len(tdev) == len(oo), name
+        c, j = tdev.lookup_host(qs[:100000])
+        e = oo.lookup_packed(qs[:100000])
+        assert (c == e[0]).all() and (j == e[1]).all(), name
+
+
 def test_table_image_export_and_import():
     """Replication across GPUs: the device image leaves one table as two plain byte arrays in caller-owned
     device buffers and becomes a table again on the importing side; same answers, same corrected records."""
