@@ -823,7 +823,7 @@ def end_to_end_cli(a, w):
         gen_s = time.time() - t0
         sizes = {"dump_bytes": os.path.getsize(dump), "fasta_bytes": os.path.getsize(fa)}
         t0 = time.perf_counter()
-        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1500, env=dict(os.environ, TALC_TIMING="1"))
+        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1500, env=dict(os.environ, TALC_TIMING=os.environ.get("TALC_E2E_TIMING", "1")))
         wall = time.perf_counter() - t0
         timing, lib_notes = None, []
         for line in p.stderr.decode(errors="replace").splitlines():
@@ -831,6 +831,8 @@ def end_to_end_cli(a, w):
                 timing = json.loads(line[len("[talc-timing] "):])
             elif line.startswith("[talc-lib] "):
                 lib_notes.append(line[len("[talc-lib] "):])
+            elif line.startswith("[talc-batch] "):
+                print(line, file=sys.stderr, flush=True)
         if p.returncode != 0 or timing is None:
             return {"error": "talc exited with %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-400:])}
         out_bytes = os.path.getsize(outp + ".fa")

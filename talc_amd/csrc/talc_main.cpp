@@ -565,6 +565,12 @@ int main(int argc, const char** argv) {
         const auto tu0 = std::chrono::steady_clock::now();
         for (uint32_t i = 0; i < n; ++i) c->out[i].assign(outb.p + oo[i], oo[i + 1] - oo[i]);
         unpackUs += usSince(tu0);
+        if (const char* tv = getenv("TALC_TIMING")) if (tv[0] == '2') {   // per batch: where this worker's time went
+          talc_timing tm; talc_ctx_get_timing(ctx, &tm);
+          fprintf(stderr, "[talc-batch] reads %u: create+H2D %.3f s, correct %.3f s (kernels: coverage %.1f structure %.1f search %.1f retry %.1f ms), fetch %.3f s, strings %.3f s\n",
+                  n, std::chrono::duration<double>(tk0 - td0).count(), std::chrono::duration<double>(tf0 - tk0).count(), tm.coverage_ms, tm.structure_ms, tm.search_ms, tm.retry_ms,
+                  std::chrono::duration<double>(tu0 - tf0).count(), usSince(tu0) / 1e6);
+        }
         if (crc > 0) for (uint32_t i = 0; i < n; ++i) readErrors += c->status[i] == TALC_READ_ERROR ? 1 : 0;
         talc_batch_destroy(b);
       }
