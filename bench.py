@@ -555,9 +555,10 @@ def committed_pmc(lib_hash, w, reads_rank):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("lib_source_hash") != lib_hash or pmc.get("baseline_config") != w["config"] or pmc.get("reads") != reads_rank:
+        entry = pmc.get("configs", {}).get(str(w["config"]))
+        if pmc.get("lib_source_hash") != lib_hash or not entry or entry.get("reads") != reads_rank or "custom" in w["label"]:
             return {}
-        return {k: 1024.0 * (pmc[k]["FETCH_SIZE_KB"] + pmc[k]["WRITE_SIZE_KB"]) for k in ("k_coverage", "k_search") if k in pmc}
+        return {k: 1024.0 * (entry[k]["FETCH_SIZE_KB"] + entry[k]["WRITE_SIZE_KB"]) for k in ("k_coverage", "k_search") if k in entry}
     except (OSError, KeyError, ValueError, TypeError):
         return {}
 

@@ -2157,7 +2157,7 @@ TALC_D int step_bridge(int nCur, int len, uint32_t& stepCounter) {
     PROF_END(PF_PROBE);
     const int cnt = min(64, nCur - base);
     X.steps += (unsigned long long)cnt;
-    if (byLane) {
+    if (byLane && nCur > 1) {   // (one Trail: the sequential form is as quick, and a call saves and restores 17 registers)
       PROF_BEGIN();
       const int nn = uni(bridge_children_by_lane(mine.tags, mine.nc[0], mine.nc[1], mine.nc[2], mine.nc[3], base, cnt, len, nNew));
       PROF_END(PF_CHILD);
