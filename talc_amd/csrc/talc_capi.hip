@@ -770,7 +770,7 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&c->d_hist, 1024 * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&c->d_counters, (64 + 2 * 8192) * sizeof(uint64_t)));   // 64 counters + the profile build's record of every wave's last read
+  HIPCHK(hipMalloc((void**)&c->d_counters, (128 + 2 * 8192) * sizeof(uint64_t)));   // 128 counters + the profile build's record of every wave's last read
   {   // isExpectedbyMyModel as two thresholds per count (Explorer.cpp:1185-1201), from the formula itself, for this ALPHA
     const uint32_t n = 4096;
     HIPCHK(hipMalloc((void**)&c->d_thr, 2ull * n * sizeof(uint32_t)));

@@ -666,14 +666,14 @@ enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN
        PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
        PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX,
        PF_XSTAGE, PF_XLEV, PF_XSEL, PF_REFB, PF_RESULT, PF_CYQ, PF_CYX, PF_CYHIT, PF_CYFILL,
-       PF_SB11, PF_SB12, PF_SB21, PF_SB10, PF_SBOTHER, PF_SEGEN, PF_XCALLS, PF_XNLEV, PF_FSFORK, PF_FSDEAD, PF_FSFILT, PF_FSLIM, PF_FK1, PF_FK2, PF_FKBAIL, PF_FORK, PF_N };
+       PF_SB11, PF_SB12, PF_SB21, PF_SB10, PF_SBOTHER, PF_SEGEN, PF_XCALLS, PF_XNLEV, PF_FSFORK, PF_FSDEAD, PF_FSFILT, PF_FSLIM, PF_FK1, PF_FK2, PF_FKBAIL, PF_FORK, PF_ANCCALLS, PF_ANCITER, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
                        "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
                        "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords", "#reads<0.25ms", "#reads<1ms", "#reads<4ms", \
                        "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)", "x.stage", "x.levels", "x.select", "b.ref", "b.result", \
                        "#cyc.query", "#cyc.exact", "#cyc.found", "cyc.fill%sum", \
                        "#stepb 1->1", "#stepb 1->2", "#stepb 2->1", "#stepb 1->0", "#stepb other", "#stepe generic", "#xdrop calls", "#xdrop levels", \
-                       "#ffstop fork", "#ffstop deadend", "#ffstop filter", "#ffstop limit/other", "#forkstep 1 child", "#forkstep fork+deadend", "#forkstep bailed", "forkstep"}
+                       "#ffstop fork", "#ffstop deadend", "#ffstop filter", "#ffstop limit/other", "#forkstep 1 child", "#forkstep fork+deadend", "#forkstep bailed", "forkstep", "#anchor lists", "#anchor level tests"}
 
 struct Wv {
   // kernel constants
@@ -1182,6 +1182,9 @@ TALC_D bool build_anchors_body(int side) {
 #define RUNY(pos) ((LEAF || inRegs) ? run_y(pos) : (clean ? (*(const v2u32 TALC_AS1*)(cr.hits + hbase + ((pos) - rs))).y : COVY(pos)))
 #define HEADX(a) (((a) < (uint32_t)kHeadCov) ? (uint32_t)uni((int)park[128u + (a)]) : (LEAF ? 0u : COVX(a)))
   uint32_t current_count = (uint32_t)uni((int)RUNX(pivot));
+#ifdef TALC_PROF
+  if (l == 0) g_prof[PF_ANCCALLS] += 1;
+#endif
   uint32_t nPos = 0;
   if (l == 0) anchorPos[0] = pivot;
   nPos = 1;
@@ -1197,6 +1200,9 @@ TALC_D bool build_anchors_body(int side) {
       const bool inRange = valid & (nc >= MINC) & ((double)nc < P.MAX_IN_COUNT);
       int from = 0;
       while (from < 64) {
+#ifdef TALC_PROF
+        if (l == 0) g_prof[PF_ANCITER] += 1;
+#endif
         const bool go = inRange && is_expected_by_last_node(P.ALPHA, nc, current_count);
         const unsigned long long stops = ballot64(valid && !go) & (~0ull << from);
         if (stops == 0ull) break;
@@ -3531,16 +3537,16 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     g_prof[PF_XSTAGE] = g_wprof[0]; g_prof[PF_XLEV] = g_wprof[1]; g_prof[PF_XSEL] = g_wprof[2]; g_prof[PF_XNLEV] = g_wprof[3];
     {   // wave utilisation of the launch: sum of the waves' lifetimes against (last end - first start) x waves
       const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-      atomicAdd((unsigned long long*)&counters[61], r1 - _pf_r0);   // (counters[2 .. 2 + PF_N) are the categories)
-      atomicMin((unsigned long long*)&counters[62], _pf_r0);
-      atomicMax((unsigned long long*)&counters[63], r1);
+      atomicAdd((unsigned long long*)&counters[125], r1 - _pf_r0);   // (counters[2 .. 2 + PF_N) are the categories)
+      atomicMin((unsigned long long*)&counters[126], _pf_r0);
+      atomicMax((unsigned long long*)&counters[127], r1);
       // the wave's last read: (queue position, read), (its start, the wave's end) — TALC_PROF_SLOW prints the waves that end last
       if (_pf_rd0) state[_pf_prevR].pfTicks = (uint32_t)(r1 - _pf_rd0);
       if (blockIdx.x < 8192u) {
-        counters[64 + 2 * blockIdx.x] = ((unsigned long long)_pf_prevQi << 32) | _pf_prevR;
-        counters[65 + 2 * blockIdx.x] = ((_pf_rd0 & 0xFFFFFFFFull) << 32) | (r1 & 0xFFFFFFFFull);
+        counters[128 + 2 * blockIdx.x] = ((unsigned long long)_pf_prevQi << 32) | _pf_prevR;
+        counters[129 + 2 * blockIdx.x] = ((_pf_rd0 & 0xFFFFFFFFull) << 32) | (r1 & 0xFFFFFFFFull);
       }
-      static_assert(2 + PF_N <= 61, "the profile categories run into the utilisation counters");
+      static_assert(2 + PF_N <= 125, "the profile categories run into the utilisation counters");
     }
     for (int i = 0; i < PF_N; ++i) {
       if (i == PF_RDMAX) atomicMax((unsigned long long*)&counters[2 + i], (unsigned long long)g_prof[i]);
