@@ -11,7 +11,7 @@ rocprofv3 -L > "$O/${TAG}_counters_list.txt" 2>&1 || true
 i=0
 for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  timeout -k 10 250 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/${TAG}_$i" -o pmc -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu --no-h2h --no-paralog > "$O/${TAG}_$i.json" 2> "$O/${TAG}_$i.err" || { echo "pass $i failed"; tail -5 "$O/${TAG}_$i.err"; exit 1; }
+  timeout -k 10 250 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/${TAG}_$i" -o pmc -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu --no-h2h --no-paralog --no-e2e > "$O/${TAG}_$i.json" 2> "$O/${TAG}_$i.err" || { echo "pass $i failed"; tail -5 "$O/${TAG}_$i.err"; exit 1; }
   echo "pass $i done"
 done
 python3 - "$TAG" <<'PY'

@@ -662,7 +662,25 @@ int talc_table_import_device(const talc_params* p, uint64_t capacity, uint64_t n
   if (e == hipSuccess) e = hipMemcpy(t->stR, src_right, bytes, hipMemcpyDeviceToDevice);
   if (e == hipSuccess) e = hipMemcpy(t->stL, src_left, bytes, hipMemcpyDeviceToDevice);
   if (e == hipSuccess) e = hipDeviceSynchronize();
+  // an image carries no parameters of its own: what the kernels rely on — every stored count >= MIN_COUNT, keys of K - 1
+  // bases — is checked against the parameters given (an image filtered with a lower MIN_COUNT would give wrong regions)
+  unsigned long long chk[2] = {~0ull, 0ull};
+  unsigned long long* dChk = nullptr;
+  if (e == hipSuccess) e = hipMalloc((void**)&dChk, sizeof chk);
+  if (e == hipSuccess) e = hipMemcpy(dChk, chk, sizeof chk, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_image_check, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, 0, t->stR, capacity, dChk);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(chk, dChk, sizeof chk, hipMemcpyDeviceToHost);
+  hipFree(dChk);
   if (e != hipSuccess) { hipFree(t->stR); hipFree(t->stL); delete t; return fail(TALC_ERR_DEVICE, "importing the table image: %s", hipGetErrorString(e)); }
+  const unsigned long long keyBits = 2ull * (p->k - 1);
+  if ((chk[0] != ~0ull && chk[0] < p->min_count) || (keyBits < 64 && (chk[1] >> keyBits) != 0ull)) {
+    hipFree(t->stR); hipFree(t->stL); delete t;
+    return fail(TALC_ERR_INVALID, "the image does not belong to these parameters: smallest stored count %llu (MIN_COUNT %u), keys wider than %llu bits: %s",
+                chk[0] == ~0ull ? 0ull : chk[0], p->min_count, keyBits, (keyBits < 64 && (chk[1] >> keyBits) != 0ull) ? "yes" : "no");
+  }
   t->stagedDev = device;
   *out = t;
   return TALC_OK;

@@ -266,6 +266,25 @@ __global__ void k_build_walk(const Bucket* __restrict__ right, const Bucket* __r
 }
 
 
+// ==================================================================== an imported image's invariant
+// "Every stored count is >= MIN_COUNT" is what k_coverage (a hit is a table k-mer) and the walk tables' `single` flag rely
+// on, and an image carries no parameters of its own: the importer checks the smallest non-zero count of the RIGHT table and
+// the widest key against the parameters it was given (out[0] = that minimum, out[1] = the OR of all keys).
+__global__ void k_image_check(const Bucket* __restrict__ right, uint64_t cap, unsigned long long* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long mn = ~0ull, orKeys = 0ull;
+  if (i < cap && right[i].key != kEmptyKey) {
+    orKeys = right[i].key & kKeyMask;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const uint32_t c = right[i].cnt[b]; if (c != 0u && (unsigned long long)c < mn) mn = c; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long m2 = (unsigned long long)__shfl_down((long long)mn, off, 64), o2 = (unsigned long long)__shfl_down((long long)orKeys, off, 64);
+    mn = m2 < mn ? m2 : mn; orKeys |= o2;
+  }
+  if ((threadIdx.x & 63) == 0) { if (mn != ~0ull) atomicMin(&out[0], mn); if (orKeys) atomicOr(&out[1], orKeys); }
+}
+
 // ==================================================================== the text dump parsed on the device
 // `jellyfish dump -c` writes one canonical line per k-mer — K letters of ACGT, one blank, one to nine digits, a newline —
 // and a 500 M-line dump is 19 GB of them: parsed on the host (128 threads over the mapped file) that took 6.6 s of a

@@ -2779,7 +2779,7 @@ TALC_DNC int fast_forward_wide(int len, uint32_t& stepCounter, uint32_t PATH_MAX
                               : fast_forward_walk<false, true>(len, stepCounter, PATH_MAXLENGTH, edge);
 }
 TALC_DN int fast_forward(int len, uint32_t& stepCounter, uint32_t PATH_MAXLENGTH, bool edge) {
-  // the walk tables encode "count >= MIN_COUNT" for MIN_COUNT below 2^14 only (talc_common.h)
+  // the walk tables encode "count >= MIN_COUNT" for MIN_COUNT below 2^13 - 1 only (kWalkTopNone = 0x1FFF, talc_common.h)
   if (uni((int)(X.T.walkRight != nullptr && X.P.MIN_COUNT < kWalkTopNone)) != 0)
   {
     if (uni((int)X.wideMask) != 0) [[clang::musttail]] return fast_forward_wide(len, stepCounter, PATH_MAXLENGTH, edge);

@@ -961,6 +961,12 @@ def test_table_image_export_and_import():
     assert hip.hipMalloc(C.byref(br), nb) == 0 and hip.hipMalloc(C.byref(bl), nb) == 0
     pair.ttab.export_device(0, br.value, bl.value)
     t2 = T.Table.import_device(pair.p, pair.ttab.capacity, len(pair.ttab), br.value, bl.value, 0)
+    # an image carries no parameters: one filtered with MIN_COUNT 2 is refused under MIN_COUNT 3 (its counts of 2 would be
+    # "solid" k-mers of every region), and under another K (its keys are 40 bits wide)
+    for bad in (dict(k=21, min_count=3), dict(k=19)):
+        pb, _ = PU.both_params(use_junctions=1, **bad)
+        with pytest.raises(T.TalcError, match="does not belong to these parameters"):
+            T.Table.import_device(pb, pair.ttab.capacity, len(pair.ttab), br.value, bl.value, 0)
     hip.hipFree(br)
     hip.hipFree(bl)
     assert len(t2) == len(pair.ttab)
