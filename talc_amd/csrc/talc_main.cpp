@@ -30,13 +30,17 @@
 #include <iostream>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
 #include <spawn.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -174,54 +178,97 @@ void setBasicReadStatsHeader(const std::string& statFile) {
 // the format is decided by the first non-empty line ('>' or '@'); id = the whole header line after the marker;
 // multi-line sequences are concatenated; FASTQ qualities are skipped by length.  Sequences are kept as raw text:
 // the device applies the Dna5 conversion.
+// lines of a file through one large buffer (read(2) in 8 MB pieces, memchr for the line ends): the streaming reader's
+// std::getline loop was what bounded the whole correction phase once the GPU side had become quick (1 GB/s of FASTA)
+class LineReader {
+ public:
+  explicit LineReader(const std::string& file) : buf_(8u << 20) { fd_ = open(file.c_str(), O_RDONLY); }
+  ~LineReader() { if (fd_ >= 0) close(fd_); }
+  bool ok() const { return fd_ >= 0; }
+  // the next line without its "\n" / "\r\n"; the pointer is valid until the next call
+  bool getline(const char*& p, size_t& len) {
+    while (true) {
+      const char* nl = (pos_ < end_) ? (const char*)memchr(buf_.data() + pos_, '\n', end_ - pos_) : nullptr;
+      if (nl) {
+        p = buf_.data() + pos_;
+        len = (size_t)(nl - p);
+        pos_ = (size_t)(nl - buf_.data()) + 1;
+        while (len && (p[len - 1] == '\r' || p[len - 1] == '\n')) --len;
+        return true;
+      }
+      if (eof_) {
+        if (pos_ >= end_) return false;
+        p = buf_.data() + pos_; len = end_ - pos_; pos_ = end_;   // a last line without a newline
+        while (len && (p[len - 1] == '\r' || p[len - 1] == '\n')) --len;
+        return true;
+      }
+      // no line end in what is left: move the tail to the front (grow the buffer for a line longer than it) and read on
+      if (pos_ > 0) { memmove(&buf_[0], buf_.data() + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
+      if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+      const ssize_t r = read(fd_, &buf_[end_], buf_.size() - end_);
+      if (r <= 0) eof_ = true; else end_ += (size_t)r;
+    }
+  }
+
+ private:
+  int fd_ = -1;
+  std::vector<char> buf_;
+  size_t pos_ = 0, end_ = 0;
+  bool eof_ = false;
+};
+
+// FASTA / FASTQ records one by one (multi-line sequences, blank lines, CRLF), the sequence appended to any sink
 class SeqReader {
  public:
   explicit SeqReader(const std::string& file) : in_(file) {
-    if (!in_) { std::cerr << "ERROR: Could not open file " << file << "\n"; ok_ = false; return; }
-    while (std::getline(in_, line_)) {   // first non-empty line decides the format
-      chomp(line_);
-      if (line_.empty()) continue;
-      fastq_ = line_[0] == '@';
-      if (!fastq_ && line_[0] != '>') ok_ = false;
+    if (!in_.ok()) { std::cerr << "ERROR: Could not open file " << file << "\n"; ok_ = false; return; }
+    while (in_.getline(lp_, ll_)) {   // first non-empty line decides the format
+      if (ll_ == 0) continue;
+      fastq_ = lp_[0] == '@';
+      if (!fastq_ && lp_[0] != '>') ok_ = false;
       pending_ = true;
       break;
     }
   }
   bool ok() const { return ok_; }
   bool fastq() const { return fastq_; }
-  // next record; false at the end of the file (or on a malformed FASTQ header: bad() then says so)
-  bool next(std::string& id, std::string& seq) {
-    seq.clear();
+  // next record; false at the end of the file (or on a malformed FASTQ header: bad() then says so).  sink(p, n) is called
+  // with every piece of the record's sequence and returns false to stop (no memory).
+  template <class Sink>
+  bool next(std::string& id, Sink&& sink) {
     if (!ok_) return false;
     if (!pending_) {
       while (true) {
-        if (!std::getline(in_, line_)) return false;
-        chomp(line_);
-        if (fastq_ ? !line_.empty() : (!line_.empty() && line_[0] == '>')) break;
+        if (!in_.getline(lp_, ll_)) return false;
+        if (fastq_ ? ll_ != 0 : (ll_ != 0 && lp_[0] == '>')) break;
       }
     }
     pending_ = false;
     if (fastq_) {
-      if (line_[0] != '@') { ok_ = false; return false; }
-      id = line_.substr(1);
-      while (std::getline(in_, line_)) { chomp(line_); if (!line_.empty() && line_[0] == '+') break; seq += line_; }
+      if (lp_[0] != '@') { ok_ = false; return false; }
+      id.assign(lp_ + 1, ll_ - 1);
+      size_t n = 0;
+      while (in_.getline(lp_, ll_)) { if (ll_ != 0 && lp_[0] == '+') break; if (ll_ && !sink(lp_, ll_)) { ok_ = false; return false; } n += ll_; }
       size_t got = 0;
-      while (got < seq.size() && std::getline(in_, line_)) { chomp(line_); got += line_.size(); }
+      while (got < n && in_.getline(lp_, ll_)) got += ll_;
       return true;
     }
-    id = line_.substr(1);
-    while (std::getline(in_, line_)) {
-      chomp(line_);
-      if (!line_.empty() && line_[0] == '>') { pending_ = true; break; }
-      seq += line_;
+    id.assign(lp_ + 1, ll_ - 1);
+    while (in_.getline(lp_, ll_)) {
+      if (ll_ != 0 && lp_[0] == '>') { pending_ = true; break; }
+      if (ll_ && !sink(lp_, ll_)) { ok_ = false; return false; }
     }
     return true;
   }
+  bool next(std::string& id, std::string& seq) {
+    seq.clear();
+    return next(id, [&](const char* p, size_t n) { seq.append(p, n); return true; });
+  }
 
  private:
-  static void chomp(std::string& l) { while (!l.empty() && (l.back() == '\r' || l.back() == '\n')) l.pop_back(); }
-  std::ifstream in_;
-  std::string line_;
+  LineReader in_;
+  const char* lp_ = nullptr;
+  size_t ll_ = 0;
   bool ok_ = true, fastq_ = false, pending_ = false;
 };
 
@@ -247,21 +294,23 @@ struct PinnedBuf {
     p = q; cap = nc; pinned = pin;
     return true;
   }
-  bool append(const std::string& s) {
-    if (!reserve(len + s.size())) return false;
-    memcpy(p + len, s.data(), s.size());
-    len += s.size();
+  bool append(const char* s, size_t n) {
+    if (!reserve(len + n)) return false;
+    memcpy(p + len, s, n);
+    len += n;
     return true;
   }
+  bool append(const std::string& s) { return append(s.data(), s.size()); }
 };
 
 struct Chunk {
   uint64_t index = 0;
   std::vector<std::string> ids;
-  std::vector<uint64_t> offsets{0};     // into the worker's input buffer
-  std::vector<std::string> out;
+  std::vector<uint64_t> offsets{0};     // into the chunk's input buffer
+  int inBuf = -1;                       // which page-locked input buffer of the pool holds the reads
   std::vector<int32_t> status;
   std::vector<int64_t> stats;           // 5 per read (--read-stats)
+  std::string text, logText, statsText; // what the writer appends to <o>.fa / <o>.log / <o>.stats_basics.txt
 };
 
 // a Jellyfish 2 count file starts with nine digits (the header's length) and the header's opening brace (talc_jf.h)
@@ -447,73 +496,115 @@ int main(int argc, const char** argv) {
   std::ofstream of(outFile, std::ios_base::trunc);
   if (!of) { std::cerr << "ERROR: Could not open the file " << outFile << "\n"; return 2; }
 
-  // ---- the pipeline: batches of --batch-reads reads are read under a lock (input order = batch index), corrected by
-  // whichever worker took them (two workers per GPU, each with its own context and stream, so that one batch's
-  // transfers overlap the other's kernels), and written strictly in input order; at most one batch per worker is
-  // in memory.  Replaces the load-everything / OpenMP loop / write-everything of main.cpp:209-310.
+  // ---- the pipeline (replaces the load-everything / OpenMP loop / write-everything of main.cpp:209-310):
+  //   one READER thread parses batches of --batch-reads reads straight into page-locked buffers of a small pool (input order =
+  //   batch index); two WORKERS per GPU (own context and stream each: one batch's transfers run under the other's kernels)
+  //   take a batch, correct it, and turn the records into the text of <o>.fa themselves — '>' id, 70-column lines
+  //   (io.cpp:50-75) — so that formatting runs in parallel; one WRITER thread appends the finished batches' text strictly
+  //   in input order.  At most (workers + 2) batches are in flight.
   SeqReader reader(o.seqFile);
   std::atomic<bool> failed{false};
-  std::mutex rdMu, wrMu;
   uint64_t nextIndex = 0, nextToWrite = 0, basesTotal = 0;
-  std::map<uint64_t, std::unique_ptr<Chunk>> finished;
   std::ofstream lf, sf;
   std::mutex failMu;
   std::string failMsg;
   std::atomic<uint64_t> readErrors{0};
-  auto setFailed = [&]() { std::lock_guard<std::mutex> g(failMu); if (!failed) failMsg = talc_last_error(); failed = true; };
-  double readBusy = 0, writeBusy = 0;            // under rdMu / wrMu
+  const int nWorkers = emptyRun ? 1 : 2 * ndev;
+  const int nInBufs = nWorkers + 2;
+  std::vector<PinnedBuf> inBufs(nInBufs);
+  std::mutex qMu;                                   // guards everything below
+  std::condition_variable cvFree, cvReady, cvDone, cvRoom;
+  std::vector<int> freeIn;
+  for (int i = 0; i < nInBufs; ++i) freeIn.push_back(i);
+  std::deque<std::unique_ptr<Chunk>> ready;
+  bool readerDone = false;
+  std::map<uint64_t, std::unique_ptr<Chunk>> finished;
+  int workersLeft = nWorkers;
+  auto setFailed = [&]() {
+    { std::lock_guard<std::mutex> g(failMu); if (!failed) failMsg = talc_last_error(); failed = true; }
+    std::lock_guard<std::mutex> g(qMu);
+    cvFree.notify_all(); cvReady.notify_all(); cvDone.notify_all(); cvRoom.notify_all();
+  };
+  double readBusy = 0, writeBusy = 0;            // the reader's / the writer's own time
   std::atomic<long long> deviceBusyUs{0};        // summed over the workers
   std::atomic<long long> ctxUs{0}, createUs{0}, correctUs{0}, fetchUs{0}, unpackUs{0}, waitChunkUs{0};   // ... and its parts
-  auto readChunk = [&](PinnedBuf& in) -> std::unique_ptr<Chunk> {
-    std::lock_guard<std::mutex> g(rdMu);
-    const auto tr0 = std::chrono::steady_clock::now();
-    struct Acc { double& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{readBusy, tr0};
-    std::unique_ptr<Chunk> c(new Chunk());
-    std::string id, seq;
-    in.len = 0;
-    while (c->ids.size() < o.batchReads && reader.next(id, seq)) {
-      c->ids.push_back(id);
-      if (!in.append(seq)) { failed = true; return nullptr; }
-      c->offsets.push_back(in.len);
-    }
-    if (c->ids.empty()) return nullptr;
-    c->index = nextIndex++;
-    basesTotal += in.len;
-    return c;
-  };
-  auto writeReady = [&](std::unique_ptr<Chunk> c) {   // io.cpp:50-75 + SeqFileOut FASTA writer, io.cpp:105-111 log lines
-    std::lock_guard<std::mutex> g(wrMu);
-    const auto tw0 = std::chrono::steady_clock::now();
-    struct Acc { double& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{writeBusy, tw0};
-    finished[c->index] = std::move(c);
-    while (!finished.empty() && finished.begin()->first == nextToWrite) {
-      Chunk& k = *finished.begin()->second;
-      for (size_t r = 0; r < k.ids.size(); ++r) {
-        // (a read that exhausted the device scratch is written through unchanged, like any read the reference fails on:
-        //  it logs and goes on, main.cpp:298-303)
-        const char* msg = k.status[r] == TALC_READ_NO_STRUCTURE ? "Unable to define convenient structure."       // main.cpp:290
-                          : k.status[r] == TALC_READ_NO_SOLID_KMER ? "No solid kmer could be found."             // main.cpp:294
-                          : k.status[r] == TALC_READ_ERROR ? "Device scratch exhausted; read left uncorrected." : nullptr;
-        if (msg) {
-          if (!lf.is_open()) lf.open(logFile, std::ios_base::app);
-          lf << "[Read: " << k.ids[r] << " ]: " << msg << std::endl;
-        }
-        if (o.readStats && k.stats.size() == 5 * k.ids.size() && k.stats[5 * r]) {   // Read.cpp:425-431
-          if (!sf.is_open()) sf.open(statFile, std::ios_base::app);
-          sf << "\n" << k.ids[r] << "\t" << k.stats[5 * r + 1] << "\t" << k.stats[5 * r + 2] << "\t" << k.stats[5 * r + 3] << "\t" << k.stats[5 * r + 4];
-        }
-        of << '>' << k.ids[r] << '\n';   // '>' id, sequence wrapped at 70 columns
-        const std::string& q = k.out[r];
-        for (size_t p = 0; p < q.size(); p += 70) { of.write(q.data() + p, (std::streamsize)std::min<size_t>(70, q.size() - p)); of.put('\n'); }
+  auto usSince = [](std::chrono::steady_clock::time_point t) { return (long long)(1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); };
+  // what a batch's reads take, from the file's size and the scan's read count: the page-locked buffers are allocated once,
+  // at that size, by as many threads as there are buffers (an allocation of a few hundred MB takes tens of milliseconds)
+  uint64_t batchBytesEstimate = 0;
+  if (!emptyRun && nReadsTotal > 0) {
+    struct stat sbq;
+    if (stat(o.seqFile.c_str(), &sbq) == 0) batchBytesEstimate = (uint64_t)((double)sbq.st_size / (double)nReadsTotal * (double)std::min<uint64_t>(o.batchReads, nReadsTotal) * (reader.fastq() ? 0.55 : 1.05)) + (1u << 20);
+    std::vector<std::thread> th;
+    for (int i = 0; i < nInBufs; ++i) th.emplace_back([&, i] { inBufs[i].reserve(batchBytesEstimate); });
+    for (auto& t : th) t.join();
+  }
+  auto readerThread = [&]() {
+    std::string id;
+    while (!failed) {
+      int bi = -1;
+      {
+        std::unique_lock<std::mutex> g(qMu);
+        cvFree.wait(g, [&] { return failed.load() || !freeIn.empty(); });
+        if (failed) break;
+        bi = freeIn.back(); freeIn.pop_back();
       }
-      finished.erase(finished.begin());
-      ++nextToWrite;
+      const auto tr0 = std::chrono::steady_clock::now();
+      std::unique_ptr<Chunk> c(new Chunk());
+      PinnedBuf& in = inBufs[bi];
+      in.len = 0;
+      c->inBuf = bi;
+      bool bad = false;
+      while (c->ids.size() < o.batchReads && reader.next(id, [&](const char* q, size_t m) { if (!in.append(q, m)) { bad = true; return false; } return true; })) {
+        c->ids.push_back(id);
+        c->offsets.push_back(in.len);
+      }
+      readBusy += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+      if (bad) { setFailed(); break; }
+      if (c->ids.empty()) { std::lock_guard<std::mutex> g(qMu); freeIn.push_back(bi); break; }
+      c->index = nextIndex++;
+      basesTotal += in.len;
+      std::lock_guard<std::mutex> g(qMu);
+      ready.push_back(std::move(c));
+      cvReady.notify_one();
     }
+    std::lock_guard<std::mutex> g(qMu);
+    readerDone = true;
+    cvReady.notify_all();
+  };
+  // the text of one batch: '>' id, the sequence wrapped at 70 columns; the log and stats lines of its reads
+  auto formatChunk = [&](Chunk& k, const char* recs, const uint64_t* oo) {
+    const size_t n = k.ids.size();
+    size_t need = 0;
+    for (size_t r = 0; r < n; ++r) { const size_t L = (size_t)(oo[r + 1] - oo[r]); need += k.ids[r].size() + 2 + L + (L + 69) / 70; }
+    k.text.resize(need);
+    char* w = &k.text[0];
+    for (size_t r = 0; r < n; ++r) {
+      // (a read that exhausted the device scratch is written through unchanged, like any read the reference fails on:
+      //  it logs and goes on, main.cpp:298-303)
+      const char* msg = k.status[r] == TALC_READ_NO_STRUCTURE ? "Unable to define convenient structure."       // main.cpp:290
+                        : k.status[r] == TALC_READ_NO_SOLID_KMER ? "No solid kmer could be found."             // main.cpp:294
+                        : k.status[r] == TALC_READ_ERROR ? "Device scratch exhausted; read left uncorrected." : nullptr;
+      if (msg) { k.logText += "[Read: "; k.logText += k.ids[r]; k.logText += " ]: "; k.logText += msg; k.logText += '\n'; }
+      if (o.readStats && k.stats.size() == 5 * n && k.stats[5 * r]) {   // Read.cpp:425-431
+        k.statsText += "\n" + k.ids[r] + "\t" + std::to_string(k.stats[5 * r + 1]) + "\t" + std::to_string(k.stats[5 * r + 2]) + "\t" +
+                       std::to_string(k.stats[5 * r + 3]) + "\t" + std::to_string(k.stats[5 * r + 4]);
+      }
+      *w++ = '>';
+      memcpy(w, k.ids[r].data(), k.ids[r].size()); w += k.ids[r].size();
+      *w++ = '\n';
+      const char* q = recs + oo[r];
+      const size_t L = (size_t)(oo[r + 1] - oo[r]);
+      for (size_t p = 0; p < L; p += 70) { const size_t m = std::min<size_t>(70, L - p); memcpy(w, q + p, m); w += m; *w++ = '\n'; }
+    }
+    k.text.resize((size_t)(w - k.text.data()));
   };
   auto passThrough = [&](Chunk& c, const PinnedBuf& in) {
     // no table at all: pass-through with the reference's statuses (Dna5 conversion / -rev still apply)
     const size_t n = c.ids.size();
-    c.out.resize(n); c.status.assign(n, TALC_READ_SKIPPED_SHORT);
+    c.status.assign(n, TALC_READ_SKIPPED_SHORT);
+    std::string all;
+    std::vector<uint64_t> oo(n + 1, 0);
     for (size_t r = 0; r < n; ++r) {
       std::string q(in.p + c.offsets[r], c.offsets[r + 1] - c.offsets[r]);
       for (auto& ch : q) { ch = (ch == 'a' || ch == 'A') ? 'A' : (ch == 'c' || ch == 'C') ? 'C' : (ch == 'g' || ch == 'G') ? 'G' : (ch == 't' || ch == 'T') ? 'T' : 'N'; }
@@ -524,26 +615,34 @@ int main(int argc, const char** argv) {
       }
       c.status[r] = q.size() > o.p.k ? TALC_READ_NO_SOLID_KMER : TALC_READ_SKIPPED_SHORT;
       if (o.readStats) { c.stats.resize(5 * n, 0); if (q.size() > o.p.k) { c.stats[5 * r] = 1; c.stats[5 * r + 1] = (int64_t)q.size(); } }
-      c.out[r] = q;
+      all += q;
+      oo[r + 1] = all.size();
     }
+    formatChunk(c, all.data(), oo.data());
   };
   auto worker = [&](int device) {
     talc_ctx* ctx = nullptr;
-    auto usSince = [](std::chrono::steady_clock::time_point t) { return (long long)(1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); };
     { const auto tc0 = std::chrono::steady_clock::now();
-      if (device >= 0 && talc_ctx_create(table, &o.p, device, &ctx) != TALC_OK) { setFailed(); return; }
+      if (device >= 0 && talc_ctx_create(table, &o.p, device, &ctx) != TALC_OK) { setFailed(); }
       ctxUs += usSince(tc0); }
-    PinnedBuf in, outb;
+    PinnedBuf outb;
+    if (device >= 0 && batchBytesEstimate) outb.reserve(batchBytesEstimate + batchBytesEstimate / 16);   // (one page-locked allocation, not a dozen doublings)
     while (!failed) {
       const auto tw0 = std::chrono::steady_clock::now();
-      std::unique_ptr<Chunk> c = readChunk(in);
+      std::unique_ptr<Chunk> c;
+      {
+        std::unique_lock<std::mutex> g(qMu);
+        cvReady.wait(g, [&] { return failed.load() || !ready.empty() || readerDone; });
+        if (failed || ready.empty()) break;
+        c = std::move(ready.front()); ready.pop_front();
+      }
       waitChunkUs += usSince(tw0);
-      if (!c) break;
+      PinnedBuf& in = inBufs[c->inBuf];
       if (device < 0) {
         passThrough(*c, in);
       } else {
         const uint32_t n = (uint32_t)c->ids.size();
-        c->out.resize(n); c->status.assign(n, TALC_READ_SKIPPED_SHORT);
+        c->status.assign(n, TALC_READ_SKIPPED_SHORT);
         talc_batch* b = nullptr;
         const auto td0 = std::chrono::steady_clock::now();
         struct Acc { std::atomic<long long>& a; std::chrono::steady_clock::time_point t; ~Acc() { a += (long long)(1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } acc{deviceBusyUs, td0};
@@ -563,26 +662,58 @@ int main(int argc, const char** argv) {
         if (o.readStats) { c->stats.resize(5ull * n); if (talc_batch_fetch_read_stats(ctx, b, c->stats.data()) != TALC_OK) { setFailed(); talc_batch_destroy(b); break; } }
         fetchUs += usSince(tf0);
         const auto tu0 = std::chrono::steady_clock::now();
-        for (uint32_t i = 0; i < n; ++i) c->out[i].assign(outb.p + oo[i], oo[i + 1] - oo[i]);
+        formatChunk(*c, outb.p, oo.data());
         unpackUs += usSince(tu0);
         if (const char* tv = getenv("TALC_TIMING")) if (tv[0] == '2') {   // per batch: where this worker's time went
           talc_timing tm; talc_ctx_get_timing(ctx, &tm);
-          fprintf(stderr, "[talc-batch] reads %u: create+H2D %.3f s, correct %.3f s (kernels: coverage %.1f structure %.1f search %.1f retry %.1f ms), fetch %.3f s, strings %.3f s\n",
+          fprintf(stderr, "[talc-batch] reads %u: create+H2D %.3f s, correct %.3f s (kernels: coverage %.1f structure %.1f search %.1f retry %.1f ms), fetch %.3f s, text %.3f s\n",
                   n, std::chrono::duration<double>(tk0 - td0).count(), std::chrono::duration<double>(tf0 - tk0).count(), tm.coverage_ms, tm.structure_ms, tm.search_ms, tm.retry_ms,
                   std::chrono::duration<double>(tu0 - tf0).count(), usSince(tu0) / 1e6);
         }
         if (crc > 0) for (uint32_t i = 0; i < n; ++i) readErrors += c->status[i] == TALC_READ_ERROR ? 1 : 0;
         talc_batch_destroy(b);
       }
-      writeReady(std::move(c));
+      std::unique_lock<std::mutex> g(qMu);
+      freeIn.push_back(c->inBuf); c->inBuf = -1;
+      cvFree.notify_one();
+      // (the batch the writer waits for always gets in; the others wait while the writer is more than a few batches behind)
+      cvRoom.wait(g, [&] { return failed.load() || c->index == nextToWrite || finished.size() < (size_t)nWorkers + 2; });
+      finished[c->index] = std::move(c);
+      cvDone.notify_one();
     }
     if (ctx) talc_ctx_destroy(ctx);
+    std::lock_guard<std::mutex> g(qMu);
+    --workersLeft;
+    cvDone.notify_all();
+  };
+  auto writerThread = [&]() {   // io.cpp:50-75 + SeqFileOut FASTA writer, io.cpp:105-111 log lines
+    while (true) {
+      std::unique_ptr<Chunk> c;
+      {
+        std::unique_lock<std::mutex> g(qMu);
+        cvDone.wait(g, [&] { return (!finished.empty() && finished.begin()->first == nextToWrite) || workersLeft == 0 || failed.load(); });
+        if (!finished.empty() && finished.begin()->first == nextToWrite) { c = std::move(finished.begin()->second); finished.erase(finished.begin()); }
+        else if (workersLeft == 0 || failed) break;
+      }
+      if (!c) continue;
+      const auto tw0 = std::chrono::steady_clock::now();
+      if (!c->logText.empty()) { if (!lf.is_open()) lf.open(logFile, std::ios_base::app); lf << c->logText; lf.flush(); }
+      if (!c->statsText.empty()) { if (!sf.is_open()) sf.open(statFile, std::ios_base::app); sf << c->statsText; }
+      of.write(c->text.data(), (std::streamsize)c->text.size());
+      writeBusy += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+      std::lock_guard<std::mutex> g(qMu);
+      ++nextToWrite;
+      cvRoom.notify_all();
+    }
   };
   {
+    std::thread rd(readerThread), wr(writerThread);
     std::vector<std::thread> workers;
     if (emptyRun) workers.emplace_back(worker, -1);
     else for (int d = 0; d < ndev; ++d) for (int w = 0; w < 2; ++w) workers.emplace_back(worker, d % nphys);
     for (auto& w : workers) w.join();
+    rd.join();
+    wr.join();
   }
   of.close();
   auto t3 = std::chrono::steady_clock::now();
@@ -601,7 +732,7 @@ int main(int argc, const char** argv) {
           (unsigned long long)nextIndex, o.batchReads, secs(t0, t3));
   fprintf(stderr, "[talc-timing] {\"scan_s\": %.4f, \"table_parse_build_s\": %.4f, \"upload_s\": %.4f, \"correct_phase_s\": %.4f, "
                   "\"reader_busy_s\": %.4f, \"device_busy_s_sum_over_workers\": %.4f, \"writer_busy_s\": %.4f, \"total_s\": %.4f, "
-                  "\"device_parts_s\": {\"ctx_create\": %.4f, \"batch_create_h2d\": %.4f, \"correct\": %.4f, \"fetch_d2h\": %.4f, \"records_to_strings\": %.4f, \"waiting_for_reader\": %.4f}, "
+                  "\"device_parts_s\": {\"ctx_create\": %.4f, \"batch_create_h2d\": %.4f, \"correct\": %.4f, \"fetch_d2h\": %.4f, \"records_to_text\": %.4f, \"waiting_for_reader\": %.4f}, "
                   "\"reads\": %llu, \"bases\": %llu, \"batches\": %llu, \"batch_reads\": %u, \"gpus\": %d, \"workers\": %d}\n",
           secs(t0, t1), secs(t1, t2), secs(t2, t2b), secs(t2b, t3), readBusy, (double)deviceBusyUs.load() / 1e6, writeBusy, secs(t0, t3),
           ctxUs.load() / 1e6, createUs.load() / 1e6, correctUs.load() / 1e6, fetchUs.load() / 1e6, unpackUs.load() / 1e6, waitChunkUs.load() / 1e6,
