@@ -524,44 +524,54 @@ TALC_D unsigned ffbl_raw(unsigned x) {
   asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
   return r;
 }
-TALC_D unsigned wfa_equal_prefix8(unsigned long long x, unsigned long long y) {   // number of equal leading (low) bytes, 0..8
+// position of the first differing byte of two 8-byte words x 8, as the hardware's find-first-bit gives it: 0 .. 63 (bits
+// below the first differing byte's: >> 3 = equal leading bytes), or 0xFFFFFFFF when the words agree
+TALC_D unsigned wfa_first_diff_raw(unsigned long long x, unsigned long long y) {
   const unsigned long long w = x ^ y;
-  const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
-  // an all-equal half gives 0xFFFFFFFF (unchanged by the "| 32"), which loses every min below
-  const unsigned t = min(ffbl_raw(lo), ffbl_raw(hi) | 32u);
-  return min(t >> 3, 8u);
+  // an all-equal half gives 0xFFFFFFFF (unchanged by the "| 32"), which loses the min
+  return min(ffbl_raw((unsigned)w), ffbl_raw((unsigned)(w >> 32)) | 32u);
 }
+TALC_D unsigned wfa_equal_prefix8(unsigned long long x, unsigned long long y) {   // number of equal leading (low) bytes, 0..8
+  return min(wfa_first_diff_raw(x, y) >> 3, 8u);
+}
+// (Whether a lane goes on is carried as the raw value t of its last comparison — "t > 63" is a plain compare whose ballot
+//  is the compare's own lane mask; a boolean carried through the divergent rounds costs a select and a second compare per
+//  test.  The database address is the query address plus a per-lane constant: a + k is even on every cell of diagonal k.)
 template <int NR>
 TALC_D void wfa_extend(const uint8_t TALC_AS3* stage, int qpad, int kmin, int (&a)[NR], bool (&act)[NR]) {
   const int l = lane_id();
-  unsigned qa[NR], da[NR];
-  bool any = false;
+  unsigned qa[NR], da[NR], t[NR];
 #pragma unroll
   for (int s = 0; s < NR; ++s) {
     const int k = kmin + 64 * s + l;
-    qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
+    qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = qa[s] + (unsigned)(qpad - k);
+    t[s] = 0u;
     if (act[s]) {
-      const unsigned n = wfa_equal_prefix8(lds_load_u64(stage + qa[s]), lds_load_u64(stage + da[s]));
-      a[s] += 2 * (int)n; qa[s] += 8; da[s] += 8;
-      act[s] = (n == 8u);
+      t[s] = wfa_first_diff_raw(lds_load_u64(stage + qa[s]), lds_load_u64(stage + da[s]));
+      a[s] += 2 * (int)min(t[s] >> 3, 8u); qa[s] += 8; da[s] += 8;
     }
-    any |= act[s];
   }
-  while (ballot64(any) != 0ull) {
-    any = false;
+  while (true) {
+    unsigned long long more = 0ull;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) more |= ballot64(t[s] > 63u);
+    if (more == 0ull) break;
 #pragma unroll
     for (int s = 0; s < NR; ++s) {
-      if (act[s]) {
+      const bool go = t[s] > 63u;
+      t[s] = 0u;
+      if (go) {
         const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
         const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
-        const unsigned n0 = wfa_equal_prefix8(q0, d0), n1 = wfa_equal_prefix8(q1, d1);
-        const unsigned n = (n0 == 8u) ? 8u + n1 : n0;
+        const unsigned t0 = wfa_first_diff_raw(q0, d0), t1 = wfa_first_diff_raw(q1, d1);
+        const unsigned n = (t0 > 63u) ? 8u + min(t1 >> 3, 8u) : (t0 >> 3);
         a[s] += 2 * (int)n; qa[s] += 16; da[s] += 16;
-        act[s] = (n == 16u);
-        any |= act[s];
+        t[s] = min(t0, t1);   // both words agreed: on to the next sixteen bases
       }
     }
   }
+#pragma unroll
+  for (int s = 0; s < NR; ++s) act[s] = false;
 }
 
 // ---- where the anti-diagonal loop of the original stops, and the cell it reports (talc_wfa.h), given the furthest
@@ -782,6 +792,7 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
   int eLast = eStart - 1;
   for (int e = eStart; e <= eEnd && !cornerHit; ++e) {
     if (NR == 1 && tracking && e == x) { keep_level(e - 1); tracking = false; }   // level x is the one x itself shapes (forb)
+    const bool forbLevel = (e == bmax + 1);
     int rotR[NR], rotL[NR];
 #pragma unroll
     for (int s = 0; s < NR; ++s) { rotR[s] = lane_ror1(F[s]); rotL[s] = lane_rol1(F[s]); }
@@ -797,7 +808,9 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
         int v2 = fl + 1; v2 = (v2 <= amax[s]) ? v2 : NEG;       // gap along the query
         int v3 = fr + 1; v3 = (v3 <= amax[s]) ? v3 : NEG;       // gap along the database
         int v = max(max(v2, v3), min(F[s] + 2, amax[s]));       // mismatch (clamps to F itself at the matrix end)
-        v = (v == forb[s]) ? NEG : v;
+        // (the border cell the x-drop leaves uninitialised is cell |k| of diagonal |k| = bmax + 1: level e reaches diagonals
+        //  |k| <= e only, and a diagonal enters at its cell |k|, so the test can only ever hit at level bmax + 1)
+        if (forbLevel) v = (v == forb[s]) ? NEG : v;
         b[s] = v;
         act[s] = (v > F[s]) & (v >= 0);
       }
@@ -806,7 +819,8 @@ TALC_D int wave_xdrop_wfa(const uint8_t* __restrict__ querySeg_, int qlen, const
 #pragma unroll
     for (int s = 0; s < NR; ++s) moved[s] = act[s];
     extend(b, act);
-    if (NR == 1 && tracking && ballot64(moved[0] && b[0] == aq) != 0ull) {   // this level meets the query's end: keep the one before
+    // (a lane whose candidate did not move it has b <= F < aq while no lane has met the query's end yet: the plain compare says it)
+    if (NR == 1 && tracking && ballot64(b[0] == aq) != 0ull) {   // this level meets the query's end: keep the one before
       keep_level(e - 1);
       tracking = false;
     }
