@@ -103,7 +103,7 @@ def build_hip(force=False, extra_flags=(), name="libtalc_hip.so"):
     _build_if_stale(tgt, _deps(*HIP_SOURCES),
                     [HIPCC, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-shared", "-fopenmp",
                      "-ffp-contract=off", "-fno-gpu-rdc",
-                     "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC, *extra_flags, *srcs, "-o", tgt],
+                     "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-pass-failed", "-I", INCLUDE, "-I", CSRC, *extra_flags, *srcs, "-o", tgt],
                     force)
     return tgt
 
