@@ -540,38 +540,59 @@ TALC_D unsigned wfa_equal_prefix8(unsigned long long x, unsigned long long y) { 
 template <int NR>
 TALC_D void wfa_extend(const uint8_t TALC_AS3* stage, int qpad, int kmin, int (&a)[NR], bool (&act)[NR]) {
   const int l = lane_id();
-  unsigned qa[NR], da[NR], t[NR];
-#pragma unroll
-  for (int s = 0; s < NR; ++s) {
-    const int k = kmin + 64 * s + l;
-    qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = qa[s] + (unsigned)(qpad - k);
-    t[s] = 0u;
-    if (act[s]) {
-      t[s] = wfa_first_diff_raw(lds_load_u64(stage + qa[s]), lds_load_u64(stage + da[s]));
-      a[s] += 2 * (int)min(t[s] >> 3, 8u); qa[s] += 8; da[s] += 8;
+  if constexpr (NR == 1) {
+    // the one-diagonal-per-lane instance (two thirds of all levels): as above
+    const int k = kmin + l;
+    unsigned qa = (unsigned)((a[0] + k) >> 1), da = qa + (unsigned)(qpad - k), t = 0u;
+    if (act[0]) {
+      t = wfa_first_diff_raw(lds_load_u64(stage + qa), lds_load_u64(stage + da));
+      a[0] += 2 * (int)min(t >> 3, 8u); qa += 8; da += 8;
     }
-  }
-  while (true) {
-    unsigned long long more = 0ull;
-#pragma unroll
-    for (int s = 0; s < NR; ++s) more |= ballot64(t[s] > 63u);
-    if (more == 0ull) break;
-#pragma unroll
-    for (int s = 0; s < NR; ++s) {
-      const bool go = t[s] > 63u;
-      t[s] = 0u;
+    while (ballot64(t > 63u) != 0ull) {
+      const bool go = t > 63u;
+      t = 0u;
       if (go) {
-        const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
-        const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
+        const unsigned long long q0 = lds_load_u64(stage + qa), d0 = lds_load_u64(stage + da);
+        const unsigned long long q1 = lds_load_u64(stage + qa + 8), d1 = lds_load_u64(stage + da + 8);
         const unsigned t0 = wfa_first_diff_raw(q0, d0), t1 = wfa_first_diff_raw(q1, d1);
         const unsigned n = (t0 > 63u) ? 8u + min(t1 >> 3, 8u) : (t0 >> 3);
-        a[s] += 2 * (int)n; qa[s] += 16; da[s] += 16;
-        t[s] = min(t0, t1);   // both words agreed: on to the next sixteen bases
+        a[0] += 2 * (int)n; qa += 16; da += 16;
+        t = min(t0, t1);   // both words agreed: on to the next sixteen bases
+      }
+    }
+    act[0] = false;
+  } else {
+    // the wider instances keep the form whose registers they can afford (the raw values of every slot carried through the
+    // rounds made the two- and four-wide level loops spill: +5 GB of scratch traffic per config-2 launch)
+    unsigned qa[NR], da[NR];
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+      const int k = kmin + 64 * s + l;
+      qa[s] = (unsigned)((a[s] + k) >> 1); da[s] = (unsigned)(qpad + ((a[s] - k) >> 1));
+      if (act[s]) {
+        const unsigned n = wfa_equal_prefix8(lds_load_u64(stage + qa[s]), lds_load_u64(stage + da[s]));
+        a[s] += 2 * (int)n; qa[s] += 8; da[s] += 8;
+        act[s] = (n == 8u);
+      }
+      any |= act[s];
+    }
+    while (ballot64(any) != 0ull) {
+      any = false;
+#pragma unroll
+      for (int s = 0; s < NR; ++s) {
+        if (act[s]) {
+          const unsigned long long q0 = lds_load_u64(stage + qa[s]), d0 = lds_load_u64(stage + da[s]);
+          const unsigned long long q1 = lds_load_u64(stage + qa[s] + 8), d1 = lds_load_u64(stage + da[s] + 8);
+          const unsigned n0 = wfa_equal_prefix8(q0, d0), n1 = wfa_equal_prefix8(q1, d1);
+          const unsigned n = (n0 == 8u) ? 8u + n1 : n0;
+          a[s] += 2 * (int)n; qa[s] += 16; da[s] += 16;
+          act[s] = (n == 16u);
+          any |= act[s];
+        }
       }
     }
   }
-#pragma unroll
-  for (int s = 0; s < NR; ++s) act[s] = false;
 }
 
 // ---- where the anti-diagonal loop of the original stops, and the cell it reports (talc_wfa.h), given the furthest
