@@ -570,6 +570,8 @@ def host_to_host(T, table, params, dev, bases, offs, passes, log):
     H2D / D2H copies run under the other's kernels: the streaming form the CLI uses (io.cpp:26-75 replaced)."""
     n = len(offs) - 1
     nsub = 4 if n >= 400_000 else (2 if n >= 4000 else 1)   # (small sub-batches leave k_search's waves a long tail)
+    if os.environ.get("TALC_H2H_SUB"):
+        nsub = max(1, int(os.environ["TALC_H2H_SUB"]))         # (experiments)
     cuts = [n * i // nsub for i in range(nsub + 1)]
     subs, pins = [], []
     for i in range(nsub):
