@@ -1710,11 +1710,13 @@ struct StepTags { int tags; uint32_t nc[4]; };   // (a child's distance term is 
                                                  //  doubles per lane less to carry through the step's calls)
 
 // isExpectedbyMyModel's thresholds for tagNextNodes of a tip with count `count` (talc_common.h: DevParams.thr); only
-// meaningful for count < thrN (lambda_noise <= count: ERR < 1)
-TALC_D ModelThresholds model_thresholds(uint32_t count) {
+// meaningful when both the count and its lambda_noise are below thrN (inTable)
+TALC_D ModelThresholds model_thresholds(uint32_t count, bool& inTable) {
   ModelThresholds m;
   const uint32_t TALC_AS1* thr = (const uint32_t TALC_AS1*)X.P.thr;
-  const uint32_t c = min(count, X.P.thrN - 1u), ln = min(lambda_noise_of(count, X.P.ERR), X.P.thrN - 1u);
+  const uint32_t lnRaw = lambda_noise_of(count, X.P.ERR);
+  inTable = (count < X.P.thrN) & (lnRaw < X.P.thrN);   // (lambda_noise exceeds the count when --SR_ERROR_RATE is above 1)
+  const uint32_t c = min(count, X.P.thrN - 1u), ln = min(lnRaw, X.P.thrN - 1u);
   m.minExpected = thr[2u * c];
   m.belowUnexpected = thr[2u * ln + 1u];
   return m;
@@ -1732,9 +1734,10 @@ TALC_D StepTags probe_and_tag(int t, bool valid, bool complex) {
     const uint32_t K = X.P.K;
     const uint64_t succN = X.dirRight ? (nm >> 1) : (nm & ((1ULL << (K - 1)) - 1));
     // the count model's two thresholds for this Trail's count are requested before the bucket, and arrive with it
-    const ModelThresholds mt = model_thresholds(lc);
+    bool inTable;
+    const ModelThresholds mt = model_thresholds(lc, inTable);
     if (!succN) dev_next_counts(X.T, km, X.dirRight, cnt, jc);
-    if (lc < X.P.thrN) tag_next_nodes_with(mt, X.P.ERR, X.P.MIN_COUNT, cnt, jc, lc, complex, tg, (double*)nullptr);
+    if (inTable) tag_next_nodes_with(mt, X.P.ERR, X.P.MIN_COUNT, cnt, jc, lc, complex, tg, (double*)nullptr);
     else tag_next_nodes(X.P.ALPHA, X.P.ERR, X.P.MIN_COUNT, cnt, jc, lc, complex, tg, ds);
   }
   r.tags = (tg[0] & 0xff) | ((tg[1] & 0xff) << 8) | ((tg[2] & 0xff) << 16) | ((tg[3] & 0xff) << 24);
@@ -2824,7 +2827,6 @@ TALC_DN int fork_step(int len_, uint32_t sc_, uint32_t PMAX_) {
   const uint64_t kmask = (1ULL << (2 * K)) - 1, m1 = (1ULL << (2 * (K - 1))) - 1;
   const uint64_t kmer = uni64(r0.kmer);
   const uint32_t cnt = (uint32_t)uni((int)r0.cnt);
-  if (cnt >= (uint32_t)uni((int)P.thrN)) return 0;   // (a count beyond the threshold table: the generic step has the formula)
   auto child_of = [&](uint64_t km, uint32_t b) -> uint64_t {
     return dirRight ? (((km << 2) | (uint64_t)b) & kmask) : (((uint64_t)b << (2 * (K - 1))) | (km >> 2));
   };
@@ -2834,7 +2836,9 @@ TALC_DN int fork_step(int len_, uint32_t sc_, uint32_t PMAX_) {
   // ---- one round of loads: the count model's thresholds for the tip's count, lane 4 the tip's successor bucket, lanes
   // b < 4 the HOME bucket of child b's successors (a child that is not followed is never looked at again; one that is
   // nearly always sits in its home bucket)
-  const ModelThresholds mtTip = model_thresholds(cnt);
+  bool tipInTable;
+  const ModelThresholds mtTip = model_thresholds(cnt, tipInTable);
+  if (uni((int)tipInTable) == 0) return 0;   // (a count beyond the threshold table: the generic step has the formula)
   const uint64_t kmMine = (l == 4) ? kmer : child_of(kmer, (uint32_t)(l & 3));
   const uint64_t keyMine = dirRight ? (kmMine & m1) : (kmMine >> 2);
   const Bucket* tab = dirRight ? X.T.right : X.T.left;

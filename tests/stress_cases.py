@@ -22,6 +22,12 @@ CASES = {
     302: (dict(target_kmers=350_000, k=29, seed=302, synth_kw=dict(paralog_frac=0.5, paralog_div=0.03, mixed_lengths=1)), dict(check_interval=5)),
     303: (dict(target_kmers=350_000, k=24, seed=303, junctions=True, synth_kw=dict(paralog_frac=0.4, paralog_div=0.06)), dict(min_count=3, max_nb_inner_paths=20)),
     304: (dict(target_kmers=350_000, k=29, seed=304, synth_kw=dict(paralog_frac=0.5, paralog_div=0.04)), dict()),
+    # parameters at the ends of their ranges
+    401: (dict(target_kmers=300_000, k=21, seed=401, synth_kw=dict(paralog_frac=0.5, paralog_div=0.04)), dict(max_nb_competing_paths=1, max_nb_inner_paths=1)),
+    402: (dict(target_kmers=300_000, k=18, seed=402, synth_kw=dict(paralog_frac=0.3, paralog_div=0.05)), dict(check_interval=1, window_size=1)),
+    403: (dict(target_kmers=300_000, k=22, seed=403, synth_kw=dict(paralog_frac=0.4, paralog_div=0.03)), dict(sr_error_rate=1.5, alpha=0.5, min_count=5)),
+    404: (dict(target_kmers=300_000, k=30, seed=404), dict(max_start_anchors=1, min_start_anchors=1, max_border_length=50, allowed_failure_rate=0.9, max_nb_border_failures=0)),
+    405: (dict(target_kmers=300_000, k=21, seed=405, junctions=True, synth_kw=dict(paralog_frac=0.4, paralog_div=0.05)), dict(max_in_count=40, coloured_count_thr=5, max_nb_border_paths=2, min_inner_score=0.95, min_border_score=0.95)),
 }
 
 

@@ -23,16 +23,17 @@ def _pair(case):
     return pair, kw
 
 
-@pytest.mark.parametrize("case,n_reads", [(103, 1500), (303, 1500), (304, 1500)],
-                         ids=["branching-MAXB8-CI4", "branching-junctions-MINC3-k24", "branching-k29"])
+@pytest.mark.parametrize("case,n_reads", [(103, 1500), (303, 1500), (304, 1500), (401, 1500), (403, 1500)],
+                         ids=["branching-MAXB8-CI4", "branching-junctions-MINC3-k24", "branching-k29", "MAXB1-INNER1", "SR_ERROR_RATE-1.5-MINC5"])
 def test_stress_draw_matches_oracle(case, n_reads):
-    """1500 reads from three of the tool's sets: MAX_NB_BRANCHES != 7 with CHECK_INTERVAL 4 (the set that found round 3's
-    bug), junction colours with MIN_COUNT 3, and K = 29."""
+    """1500 reads from five of the tool's sets: MAX_NB_BRANCHES != 7 with CHECK_INTERVAL 4 (the set that found round 3's
+    bug), junction colours with MIN_COUNT 3, K = 29, and two with parameters at the ends of their ranges (one competing path
+    and one inner path: every fork goes through scoring; an SR error rate above 1: lambda_noise exceeds the count)."""
     pair, kw = _pair(case)
     bases, offs = pair.reads(0, n_reads)
     bad, (so, ost), _ = PU.compare_correction(pair, bases, offs, nthreads=16, verbose=False)
     assert not bad, (case, bad[:5])
-    assert int(np.bincount(ost, minlength=4)[0]) > 0.9 * n_reads          # the draw really is corrected reads
+    assert int(np.bincount(ost, minlength=4)[0]) > 0.85 * n_reads         # the draw really is corrected reads
 
 
 def test_half_corrected_reads_over_a_branching_graph_match_oracle():
