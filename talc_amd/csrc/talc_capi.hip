@@ -79,6 +79,10 @@ struct Stage {
   uint64_t scratch_bytes = 0;
   uint32_t n_slots = 0;
   SearchCaps caps;
+  // edge tasks (first pass only): one box per slot + the slots' claim counters (talc_kernels_search.h, "edge tasks")
+  uint8_t* boxes = nullptr;
+  uint64_t boxes_bytes = 0;
+  uint32_t box_seq_cap = 0;
 };
 
 struct talc_ctx {
@@ -754,7 +758,7 @@ void talc_table_destroy(talc_table* t) {
 }
 
 // ------------------------------------------------------------------ context
-static void free_stage(Stage& s) { if (s.scratch) hipFree(s.scratch); s = Stage(); }
+static void free_stage(Stage& s) { if (s.scratch) hipFree(s.scratch); if (s.boxes) hipFree(s.boxes); s = Stage(); }
 
 int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** out) {
   int rc = check_params(p);
@@ -786,8 +790,8 @@ int talc_ctx_create(talc_table* t, const talc_params* p, int device, talc_ctx** 
   if (const char* e = getenv("TALC_COST_GAPCAP")) d.costGapCap = (uint32_t)strtoul(e, nullptr, 10);
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-  HIPCHK(hipMalloc((void**)&c->d_queue, 64 * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&c->d_hist, 1024 * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&c->d_queue, kQueueWords * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&c->d_hist, (1024 + 256) * sizeof(uint32_t)));   // (+ the batch's fork statistics, k_order_scale)
   HIPCHK(hipMalloc((void**)&c->d_counters, (128 + 2 * 8192) * sizeof(uint64_t)));   // 128 counters + the profile build's record of every wave's last read
   {   // isExpectedbyMyModel as two thresholds per count (Explorer.cpp:1185-1201), from the formula itself, for this ALPHA
     const uint32_t n = 4096;

@@ -44,16 +44,21 @@ struct ReadState {
   uint32_t overflow;    // OVF_* bits: scratch exhausted, read left unchanged
   uint32_t inSpan;      // sum over the IN regions of (end - start + 1), as they stand (Read.cpp:423: the stats row)
   uint32_t costEst;     // k_structure's estimate of the search's work (orders the work queue: heaviest reads first)
+  uint32_t costGap;     // ... the part of it that stands for the inner gaps (the queue's key weighs it by the batch's fork share)
 #ifdef TALC_PROF
   // profile build only (TALC_PROF_READS=file writes one row per read): the estimate's inputs and what the search took
   uint32_t pfHead, pfTail, pfGapSum, pfFork, pfSolid, pfTicks;   // pfTicks: 100 MHz
   uint32_t pfGapSq, pfGapMax, pfShortReg, pfSteps;
+  uint32_t pfEdgeTicks, pfAnchors, pfAnchorMax, pfStart;   // (pfStart: low 32 bits of the 100 MHz counter when the search took the read)   // 100 MHz ticks inside search_edge; edge anchors searched by this wave, the longest
 #endif
 };
 
 __host__ __device__ inline uint64_t out_capacity_for(uint64_t L) { return 4 * L + 1024; }
 
 struct FullMeta { uint32_t off, len; int32_t lanc, ranc; double dist; };
+
+// the work queue's counters (uint32 words; 1 KB apart: the waves without a read poll the last two while the others take reads from the first)
+static const uint32_t kQueueWords = 768, kQueueFinished = 256, kQueueOpen = 512;
 
 // per-wave scratch layout (byte offsets inside one slot)
 struct SearchLimits {   // (the part the search itself consults: a copy lives in the wave's LDS)
@@ -344,7 +349,7 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
             const uint64_t* __restrict__ koff, const uint2* __restrict__ covAll, const CovWord* __restrict__ covWords,
             const int32_t* __restrict__ n_in,
             ReadState* __restrict__ state, uint32_t* __restrict__ regions, const uint64_t* __restrict__ regoff,
-            uint32_t* __restrict__ headCov, uint32_t n_reads, TraceBuf trace, uint32_t traceRead) {
+            uint32_t* __restrict__ headCov, uint32_t n_reads, TraceBuf trace, uint32_t traceRead, uint32_t* __restrict__ batchStats) {
   const uint32_t r = blockIdx.x;
   if (r >= n_reads) return;
   const int l = lane_id();
@@ -352,7 +357,7 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
   const uint8_t* read = codes + offsets[r];
   const uint32_t L = (uint32_t)(offsets[r + 1] - offsets[r]);
   ReadState st;
-  st.status = TALC_READ_CORRECTED; st.nRegions = 0; st.lambda = (double)MINC; st.outLen = 0; st.overflow = 0; st.inSpan = 0; st.costEst = 0;
+  st.status = TALC_READ_CORRECTED; st.nRegions = 0; st.lambda = (double)MINC; st.outLen = 0; st.overflow = 0; st.inSpan = 0; st.costEst = 0; st.costGap = 0;
   if (!(L > K)) { st.status = TALC_READ_SKIPPED_SHORT; if (l == 0) state[r] = st; return; }      // main.cpp:262
   if (!(n_in[r] > 0)) { st.status = TALC_READ_NO_SOLID_KMER; if (l == 0) state[r] = st; return; }  // Read.cpp:194
   const uint32_t n = L - K + 1;
@@ -594,6 +599,9 @@ k_structure(DevParams P, TableView T, const uint8_t* __restrict__ codes, const u
     }
     const unsigned long long gq = (unsigned long long)P.costGapQuad + ((unsigned long long)P.costGapFork * nFork) / max(m, 1ull);
     unsigned long long cost = wave_sum_u64(part) + gq * min(wave_sum_u64(sq), (unsigned long long)P.costGapCap * P.costGapCap);
+    st.costGap = (uint32_t)min(cost >> 6, 0xFFFFFFFFull);
+    // the batch's sums of forking / solid k-mers (64 pairs of counters, one per read number mod 64; k_order_scale)
+    if (l == 0) { atomicAdd(&batchStats[2 * (r & 63u)], (uint32_t)min(nFork, 0xFFFFull)); atomicAdd(&batchStats[2 * (r & 63u) + 1], (uint32_t)min(m, 0xFFFFFull)); }
     const unsigned long long head = regS[0], eLast = regE[Rfinal - 1];
     const unsigned long long tail = (eLast + 1 < n) ? (unsigned long long)L - (eLast + K) : 0ull;
     if (head > 0 && head <= P.MAX_BORDER_LEN) cost += (unsigned long long)P.costEdgeLin * head + (unsigned long long)P.costEdgeQuad * head * head;
@@ -666,14 +674,16 @@ enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN
        PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
        PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX,
        PF_XSTAGE, PF_XLEV, PF_XSEL, PF_REFB, PF_RESULT, PF_CYQ, PF_CYX, PF_CYHIT, PF_CYFILL,
-       PF_SB11, PF_SB12, PF_SB21, PF_SB10, PF_SBOTHER, PF_SEGEN, PF_XCALLS, PF_XNLEV, PF_FSFORK, PF_FSDEAD, PF_FSFILT, PF_FSLIM, PF_FK1, PF_FK2, PF_FKBAIL, PF_FORK, PF_ANCCALLS, PF_ANCITER, PF_N };
+       PF_SB11, PF_SB12, PF_SB21, PF_SB10, PF_SBOTHER, PF_SEGEN, PF_XCALLS, PF_XNLEV, PF_FSFORK, PF_FSDEAD, PF_FSFILT, PF_FSLIM, PF_FK1, PF_FK2, PF_FKBAIL, PF_FORK, PF_ANCCALLS, PF_ANCITER, PF_TPUB, PF_TOWN, PF_TSTOLEN, PF_TWAIT, PF_TRUN, PF_EA0, PF_EA1, PF_EA2, PF_EA3, PF_EA4, PF_EASUM3, PF_EASUM4, PF_RANCH, PF_RANCHMAX, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
                        "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
                        "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords", "#reads<0.25ms", "#reads<1ms", "#reads<4ms", \
                        "#reads<16ms", "#reads<64ms", "#reads>=64ms", "maxread(10ns)", "x.stage", "x.levels", "x.select", "b.ref", "b.result", \
                        "#cyc.query", "#cyc.exact", "#cyc.found", "cyc.fill%sum", \
                        "#stepb 1->1", "#stepb 1->2", "#stepb 2->1", "#stepb 1->0", "#stepb other", "#stepe generic", "#xdrop calls", "#xdrop levels", \
-                       "#ffstop fork", "#ffstop deadend", "#ffstop filter", "#ffstop limit/other", "#forkstep 1 child", "#forkstep fork+deadend", "#forkstep bailed", "forkstep", "#anchor lists", "#anchor level tests"}
+                       "#ffstop fork", "#ffstop deadend", "#ffstop filter", "#ffstop limit/other", "#forkstep 1 child", "#forkstep fork+deadend", "#forkstep bailed", "forkstep", "#anchor lists", "#anchor level tests", \
+                       "#edges published", "#anchors by owner", "#anchors by others", "t.owner waits", "t.run by others", \
+                       "#edge anchors<1ms", "#edge anchors<4ms", "#edge anchors<16ms", "#edge anchors<64ms", "#edge anchors>=64ms", "ticks anchors 16-64ms", "ticks anchors>=64ms", "(per read) anchors", "(per read) longest anchor"}
 
 struct Wv {
   // kernel constants
@@ -722,6 +732,16 @@ struct Wv {
   uint8_t* refBuf;                 // the scratch buffer a search's reference is assembled in (ref points there, or into the read)
   uint32_t noForkStep;             // TALC_NO_FORKSTEP=1 (k_search flags bit 1): forks go through the generic step (A/B switch)
   uint32_t childrenByLane;         // 0 with TALC_CHILDREN_SEQ=1 (flags bit 2): the generic step makes its children one at a time
+  // edge tasks (the start anchors of a head / tail search handed to waves that have run out of reads; nullptr: none)
+  uint8_t* boxes; uint32_t* avail; uint32_t* qwords;
+  uint32_t boxBytes, boxSeqCap, nSlots, mySlot, nWork, taskMinWeak;
+  uint32_t taskHeavy;              // a border of at least this many bases is published when its search starts (reads of the queue's first round)
+  uint32_t qi, heavyUpTo;          // the current read's position in the work queue; `taskHeavy` applies below this position
+  uint32_t holding;                // this wave has had a read (the one before the read it takes now is finished)
+  uint32_t stealSeq;               // calls of edge_task_steal (which window of avail[] the next one looks at)
+  unsigned long long moreCells, moreSteps;   // of the anchors run for other waves between this wave's reads
+  uint32_t nanSeen;                // record_edge has seen a distance that is not a number (the fold is then order-dependent)
+  uint32_t taskTest;               // test hook (flags bit 3, TALC_TEST_EDGE_REDO): every anchor another wave has run is flagged for the in-order redo
 };
 
 enum { LOC_HEAD = 0, LOC_INNER = 1, LOC_TAIL = 2 };
@@ -739,16 +759,22 @@ __shared__ uint32_t g_prof[PF_N];   // per wave, in cycles: 2^32 cycles = 1.9 s 
 // ---- optional in-kernel cycle accounting (diagnostic build only: -DTALC_PROF) ----
 #ifdef TALC_PROF
 #define PROF_DECL unsigned long long _pf_t
+#define PF_EDGE_T0() (_pf_e0 = __builtin_amdgcn_s_memrealtime())
+#define PF_EDGE_T1() (_pf_edge += (uint32_t)(__builtin_amdgcn_s_memrealtime() - _pf_e0))
 #define PROF_BEGIN() (_pf_t = __builtin_amdgcn_s_memtime())
 #define PROF_END(cat) (g_prof[cat] += (uint32_t)(__builtin_amdgcn_s_memtime() - _pf_t))
 #define PROF_DECL2 unsigned long long _pf_t2
+#define PROF_COUNT(cat, n) do { if (lane_id() == 0) g_prof[cat] += (uint32_t)(n); } while (0)
 #define PROF_BEGIN2() (_pf_t2 = __builtin_amdgcn_s_memtime())
 #define PROF_END2(cat) (g_prof[cat] += (uint32_t)(__builtin_amdgcn_s_memtime() - _pf_t2))
 #else
 #define PROF_DECL
+#define PF_EDGE_T0() ((void)0)
+#define PF_EDGE_T1() ((void)0)
 #define PROF_BEGIN() ((void)0)
 #define PROF_END(cat) ((void)0)
 #define PROF_DECL2
+#define PROF_COUNT(cat, n) ((void)0)
 #define PROF_BEGIN2() ((void)0)
 #define PROF_END2(cat) ((void)0)
 #endif
@@ -1663,6 +1689,7 @@ TALC_DN void record_edge(int set_, int t_, int len0_) {
   const double score = (double)scoreI;
   const double idscore = (double)lcs / (double)max(cur.lenRefExt, cur.lenHistExt);
   const double dist = __longlong_as_double((long long)distBits);
+  if (dist != dist) X.nanSeen = 1u;
   // new sequence in growth order
   uint8_t* tmp = uni_ptr(X.edgeTmp);
   uint32_t newLen;
@@ -3211,62 +3238,395 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
 }
 
 // Explorer::searchEdge (Explorer.cpp:992-1081) after initializeHEAD / initializeTAIL
-TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+// one start anchor of an edge search: the body of searchEdge's loop (Explorer.cpp:1026-1055).  What it records is folded
+// into X.best2 / X.edgeLong / X.edgeShort by record_edge; X.overflow set: the search is void.
+TALC_D void edge_anchor_search(const AnchorRec* anchors_, int s_) {
   PROF_DECL2;
+#ifdef TALC_PROF
+  const unsigned long long _pf_a0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const DevParams& P = X.P;
+  const AnchorRec* anchors = uni_ptr(anchors_);
+  const int s = uni(s_);
   const uint32_t K = (uint32_t)uni((int)P.K);
+  const uint32_t readLen = (uint32_t)uni((int)X.L), maxInner = (uint32_t)uni((int)P.MAX_INNER_PATHS), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
+  const AnchorRec a = uni_anchor(anchors + s);
+  const uint32_t whichStart = a.pos;
+  uint32_t stepCounter = 0;
+  int xdrop = (int)((double)(int)P.CHECK_INTERVAL * P.FAILURE_RATE + 1.0);   // :1031
+  // currentGap = extractWeakBorderSequence(seq, whichStart, K, location) (:1035)
+  uint32_t gapLen;
+  X.refLen = 0;
+  X.ref = X.refBuf;
+  if (X.dirRight) {   // TAIL: anchor + suffix(seq, whichStart+K): the read's own tail, read in place
+    gapLen = readLen - (whichStart + K);
+    X.ref = const_cast<uint8_t*>(X.read) + whichStart;
+    X.refLen = readLen - whichStart;
+  } else {            // HEAD: prefix(seq, whichStart) + anchor
+    gapLen = whichStart;
+    ref_append(whichStart, whichStart + K);
+    ref_append(0, whichStart);
+  }
+  WSYNC();
+  const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
+  if (!pool_shape(PATH_MAXLENGTH)) return;
+  PROF_BEGIN2(); init_first_trail(a, anchors + s, false, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
+  int nCur = 1;
+  int len = (int)K;
+  while ((int)(nCur > 0) & (int)((uint32_t)nCur <= maxInner) & (int)((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH) & (int)(uni((int)X.overflow) == 0)) {
+    if (nCur == 1) {
+      PROF_BEGIN2();
+      const int ff = uni(fast_forward(len, stepCounter, PATH_MAXLENGTH, true));
+      len += ff;
+      PROF_END2(PF_FFWD);
+      if (ff > 0 && ((uint32_t)uni((int)stepCounter) % CHECK == 0)) {
+        // the fast-forward took the step after which scoring is due (Explorer.cpp:672-686): the one Trail stays
+        // where it is (set ia, slot 0) — score it there; five or fewer survivors means no gardening
+        PROF_BEGIN2();
+        nCur = uni(score_edges(X.ia, 1, len, xdrop));
+        PROF_END2(PF_STEPE);
+        continue;
+      }
+      if (!((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH)) break;
+    }
+    PROF_BEGIN2();
+    nCur = uni(step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop));
+    PROF_END2(PF_STEPE);
+    ++len;
+    if (uni((int)(X.traceSteps)))
+      trace_rec(TR_STEP, (int)stepCounter, nCur, X.nEdges, xdrop, 0.0, nullptr, 0, false);
+  }
+#ifdef TALC_PROF
+  if (lane_id() == 0) {
+    const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - _pf_a0;
+    const int bk = dt < 100000ull ? 0 : dt < 400000ull ? 1 : dt < 1600000ull ? 2 : dt < 6400000ull ? 3 : 4;
+    g_prof[PF_EA0 + bk] += 1;
+    if (bk == 3) g_prof[PF_EASUM3] += (uint32_t)dt;
+    if (bk == 4) g_prof[PF_EASUM4] += (uint32_t)dt;
+    g_prof[PF_RANCH] += 1; if ((uint32_t)dt > g_prof[PF_RANCHMAX]) g_prof[PF_RANCHMAX] = (uint32_t)dt;
+  }
+#endif
+}
+
+// (the copy the edge tasks call: search_edge has the body inline, as its loop always had)
+TALC_DN void edge_anchor_search_task(const AnchorRec* anchors, int s) { edge_anchor_search(anchors, s); }
+
+// ------------------------------------------------------------------ edge tasks
+// The start anchors of searchEdge (Explorer.cpp:1026: at most MAX_START_ANCHORS of them) are independent searches: each
+// starts from its own first Trail, what it records goes through recordEdge into m_shortPaths / m_longPaths, of which
+// sortOutBestBorder keeps the FIRST best by (score, distance) — a fold, so the best of every anchor, merged in anchor order
+// under the same strict comparison, is the sequential result (m_complexRegion is an OR).  A read with a 500-base head
+// and tail is ten such searches and, over a branching graph, a tenth of a second of ONE wave: the launch ended when the
+// heaviest of them did, with two thirds of the waves idle.  So: once the work queue has run dry, a wave about to start
+// an anchor publishes the anchors its search still has to do in its box (one per wave slot, in HBM), waves without a
+// read claim them one at a time, run them in their own scratch and write the anchor's best long / best short candidate
+// back; the owner claims from the same counter, waits for the claimed ones, and merges in anchor order.
+//   avail[slot]   unclaimed anchors of the slot's box (claim = atomic decrement; the claimed anchor is limit - old value)
+//   hdr.done      anchors finished (owner waits for claimed == done)
+//   qwords[256]   reads finished (a wave without a read leaves when this reaches n_work: nothing can be published any more)
+//   qwords[512]   unclaimed anchors over all boxes (a hint: whether scanning avail[] is worth it)
+// Box traffic is agent-scope dword atomics (the L2 of another XCD is not coherent with this one's for plain accesses)
+// between agent-scope fences.  A thief never waits for anything, so every wait here is bounded by one anchor's search.
+#define EDGE_BOX_ANCHORS 8
+struct EdgeBoxHdr {
+  const uint8_t* read; const uint2* cov; const CovWord* covw; double lambda;
+  uint32_t L, n, location, dirRight, Ls, Le, Rs, Re, LH, RH, weakLen, limit;
+  uint32_t done, first, pad[2];
+  AnchorRec anc[EDGE_BOX_ANCHORS];
+};
+struct EdgeBoxRes { EdgeCand best[2]; uint32_t complex, overflow, redo, pad; };
+static_assert(sizeof(EdgeCand) == 48 && sizeof(EdgeBoxRes) == 112 && sizeof(AnchorRec) == 24, "edge box records are moved as dwords");
+static_assert(offsetof(EdgeBoxHdr, anc) == 96 && sizeof(EdgeBoxHdr) == 96 + 24 * EDGE_BOX_ANCHORS, "edge box header layout");
+static const uint32_t kBoxResOff = 320, kBoxResStride = 128, kBoxSeqOff = kBoxResOff + EDGE_BOX_ANCHORS * kBoxResStride;
+__host__ __device__ inline uint64_t edge_box_bytes(uint32_t seqCap) { return (kBoxSeqOff + 2ull * EDGE_BOX_ANCHORS * seqCap + 255ull) / 256ull * 256ull; }
+
+// the launch's edge-task arguments (host -> k_search)
+struct EdgeTaskArgs {
+  uint8_t* boxes; uint32_t* avail;   // nullptr: no edge tasks in this launch
+  uint32_t seqCap;                   // bytes per box sequence
+  uint32_t minWeak;                  // a border of at least this many bases is published once the work queue is dry ...
+  uint32_t heavy, heavyRounds;       // ... and one of at least `heavy` bases from the start of its search, for the reads of the queue's first `heavyRounds` rounds
+  uint32_t lingerMod;                // one wave in so many stays when the reads are gone
+  uint32_t test;                     // TALC_TEST_EDGE_REDO
+  const uint32_t* autoSwitch;        // not null: the tasks are used when this word is not 0 (k_order_scale: the batch's graph branches)
+};
+TALC_D uint32_t aload32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TALC_D void astore32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TALC_D uint32_t aadd32(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TALC_D uint32_t axchg32(uint32_t* p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TALC_D void agent_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
+TALC_D uint8_t* edge_box(uint32_t slot) { return X.boxes + (uint64_t)slot * X.boxBytes; }
+TALC_D uint32_t* edge_box_seq(uint8_t* box, int s, int bi) { return (uint32_t*)(box + kBoxSeqOff + (uint64_t)(2 * s + bi) * X.boxSeqCap); }
+
+// X.best2 and its two sequences -> result s of the box (g_dp, free between searches, is the staging area)
+TALC_DNC void edge_box_store(uint8_t* box_, int s_, uint32_t complexFlag_) {
+  uint8_t* box = uni_ptr(box_); const int s = uni(s_);
+  const int l = lane_id();
+  LSYNC();
+  EdgeBoxRes* st = (EdgeBoxRes*)g_dp;
+  const uint32_t cap = (uint32_t)uni((int)X.boxSeqCap);
+  const bool tooLong = (X.best2[0].have && X.best2[0].len > cap) || (X.best2[1].have && X.best2[1].len > cap);
+  if (l == 0) {
+    st->best[0] = X.best2[0]; st->best[1] = X.best2[1];
+    st->complex = uni((int)complexFlag_); st->overflow = X.overflow; st->redo = (X.nanSeen != 0u || tooLong) ? 1u : 0u; st->pad = 0;
+  }
+  LSYNC();
+  uint32_t* dst = (uint32_t*)(box + kBoxResOff + (uint32_t)s * kBoxResStride);
+  if (l < (int)(sizeof(EdgeBoxRes) / 4)) astore32(dst + l, (uint32_t)g_dp[l]);
+  if (!tooLong) {
+    for (int bi = 0; bi < 2; ++bi) {
+      if (!X.best2[bi].have) continue;
+      const uint32_t nw = (X.best2[bi].len + 3u) >> 2;
+      const uint32_t* src = (const uint32_t*)uni_ptr(bi == 0 ? X.edgeLong : X.edgeShort);
+      uint32_t* q = uni_ptr(edge_box_seq(box, s, bi));
+      for (uint32_t i = (uint32_t)l; i < nw; i += 64) astore32(q + i, src[i]);
+    }
+  }
+  LSYNC();
+}
+// result s of the box -> g_dp (read it there as an EdgeBoxRes)
+TALC_D void edge_box_load(uint8_t* box, int s) {
+  const int l = lane_id();
+  LSYNC();
+  const uint32_t* src = (const uint32_t*)(box + kBoxResOff + (uint32_t)s * kBoxResStride);
+  if (l < (int)(sizeof(EdgeBoxRes) / 4)) g_dp[l] = (int)aload32(src + l);
+  LSYNC();
+}
+TALC_D void edge_box_take(uint8_t* box, int s, int bi, uint32_t len) {   // the sequence of a candidate back into the wave's own buffer
+  uint32_t* dst = (uint32_t*)uni_ptr(bi == 0 ? X.edgeLong : X.edgeShort);
+  const uint32_t* q = uni_ptr(edge_box_seq(box, s, bi));
+  const uint32_t nw = (len + 3u) >> 2;
+  for (uint32_t i = (uint32_t)lane_id(); i < nw; i += 64) dst[i] = aload32(q + i);
+}
+// results first .. limit-1 merged in order into X.best2 and the wave's two sequence buffers
+TALC_D void edge_box_fold(uint8_t* box, int first, int limit) {
+  EdgeCand best0, best1; best0.have = false; best1.have = false;
+  int win0 = -1, win1 = -1;
+  for (int s = first; s < limit; ++s) {
+    edge_box_load(box, s);
+    const EdgeBoxRes* r = (const EdgeBoxRes*)g_dp;
+    const EdgeCand c0 = r->best[0], c1 = r->best[1];
+    if (c0.have && (!best0.have || c0.score > best0.score || (c0.score == best0.score && c0.dist > best0.dist))) { best0 = c0; win0 = s; }
+    if (c1.have && (!best1.have || c1.score > best1.score || (c1.score == best1.score && c1.dist > best1.dist))) { best1 = c1; win1 = s; }
+  }
+  LSYNC();
+  X.best2[0] = best0; X.best2[1] = best1;
+  if (uni(win0) >= 0) edge_box_take(box, uni(win0), 0, best0.len);
+  if (uni(win1) >= 0) edge_box_take(box, uni(win1), 1, best1.len);
+  WSYNC();
+}
+
+TALC_D bool queue_is_dry() {
+  uint32_t v = 0;
+  if (lane_id() == 0) v = aload32(X.qwords);
+  return (uint32_t)uni((int)v) >= X.nWork;
+}
+
+// the read and the edge search a box describes -> X (g_dp is the staging area); returns the search's number of anchors
+TALC_D int edge_ctx_load(uint8_t* box) {
+  const int l = lane_id();
+  const uint32_t* box32 = (const uint32_t*)box;
+  LSYNC();
+  if (l < 24) g_dp[l] = (int)aload32(box32 + l);
+  LSYNC();
+  const EdgeBoxHdr* h = (const EdgeBoxHdr*)g_dp;
+  const int limit = uni((int)h->limit);
+  X.read = h->read; X.cov = h->cov; X.covw = h->covw; X.lambda = h->lambda; X.L = h->L; X.n = h->n;
+  X.location = (int)h->location; X.dirRight = (int)h->dirRight;
+  X.Ls = h->Ls; X.Le = h->Le; X.Rs = h->Rs; X.Re = h->Re; X.LH = h->LH; X.RH = h->RH; X.weakLen = h->weakLen;
+  X.ffPopped = false; X.tracing = false; X.traceSteps = false;
+  X.nAncL = X.dirRight ? limit : 0; X.nAncR = X.dirRight ? 0 : limit;
+  LSYNC();
+  return limit;
+}
+
+TALC_DNC bool edge_task_steal(int tries);
+
+// Anchors s0 .. limit-1 of the current edge search as tasks; X.best2 holds the fold of anchors 0 .. s0-1.
+// 1: X.best2 / edgeLong / edgeShort hold the fold of all anchors; 0: the fold of 0 .. s0-1 is back in place and the caller
+// goes on in order (or X.overflow is set)
+TALC_DNC int edge_anchors_as_tasks(const AnchorRec* anchors_, int s0_, int limit_) {
+  const AnchorRec* anchors = uni_ptr(anchors_);
+  const int s0 = uni(s0_), limit = uni(limit_);
+  const int l = lane_id();
+  const uint32_t me = (uint32_t)uni((int)X.mySlot);
+  uint8_t* box = uni_ptr(edge_box(me));
+  uint32_t* box32 = (uint32_t*)box;
+  uint32_t* done = box32 + offsetof(EdgeBoxHdr, done) / 4;
+  const int first = s0 > 0 ? s0 - 1 : s0;
+  if (s0 > 0) {   // the fold so far takes the place of the last anchor it covers (if a box sequence holds it)
+    const uint32_t cap = (uint32_t)uni((int)X.boxSeqCap);
+    if ((X.best2[0].have && X.best2[0].len > cap) || (X.best2[1].have && X.best2[1].len > cap)) return 0;
+    edge_box_store(box, s0 - 1, 0u);
+  }
+  LSYNC();
+  {
+    EdgeBoxHdr* h = (EdgeBoxHdr*)g_dp;
+    if (l == 0) {
+      h->read = X.read; h->cov = X.cov; h->covw = X.covw; h->lambda = X.lambda;
+      h->L = X.L; h->n = X.n; h->location = (uint32_t)X.location; h->dirRight = (uint32_t)X.dirRight;
+      h->Ls = X.Ls; h->Le = X.Le; h->Rs = X.Rs; h->Re = X.Re; h->LH = X.LH; h->RH = X.RH; h->weakLen = X.weakLen; h->limit = (uint32_t)limit;
+      h->done = 0; h->first = (uint32_t)s0; h->pad[0] = 0; h->pad[1] = 0;
+    }
+    LSYNC();
+    if (l < 24) astore32(box32 + l, (uint32_t)g_dp[l]);
+    for (int i = l; i < 6 * limit; i += 64) astore32(box32 + 24 + i, ((const uint32_t*)anchors)[i]);
+    LSYNC();
+  }
+  agent_fence();
+  const uint32_t nTasks = (uint32_t)(limit - s0);
+  if (l == 0) { aadd32(X.qwords + kQueueOpen, nTasks); (void)axchg32(X.avail + me, nTasks); }
+  PROF_COUNT(PF_TPUB, 1);
+  uint32_t nMine = 0;
+  while (true) {
+    int old = 0;
+    if (l == 0) old = (int)aadd32(X.avail + me, 0xFFFFFFFFu);
+    old = uni(old);
+    if (old <= 0) break;
+    if (l == 0) (void)aadd32(X.qwords + kQueueOpen, 0xFFFFFFFFu);
+    ++nMine;
+    PROF_COUNT(PF_TOWN, 1);
+    const int s = limit - old;
+    X.best2[0].have = false; X.best2[1].have = false; X.nanSeen = 0u;
+    edge_anchor_search_task(anchors, s);
+    edge_box_store(box, s, 0u);
+    if (uni((int)X.overflow)) break;
+  }
+  int rest = 0;
+  if (l == 0) { rest = (int)axchg32(X.avail + me, 0u); if (rest < 0) rest = 0; if (rest > 0) (void)aadd32(X.qwords + kQueueOpen, (uint32_t)(-rest)); }
+  rest = uni(rest);
+  const uint32_t expected = nTasks - (uint32_t)rest - nMine;   // (the anchors other waves have claimed)
+  PROF_COUNT(PF_TSTOLEN, expected);
+  {   // wait for the anchors other waves have claimed.  (Not by running other searches' anchors meanwhile: the wave of a heavy
+      // read that waits a millisecond for its last anchor and takes a 40 ms one from elsewhere has moved the launch's end.)
+    PROF_DECL; PROF_BEGIN();
+    if (l == 0) { while (aload32(done) < expected) __builtin_amdgcn_s_sleep(32); }
+    WSYNC();
+    PROF_END(PF_TWAIT);
+  }
+  agent_fence();
+  if (uni((int)X.overflow)) return 0;
+  uint32_t ovf = 0, redo = 0, cx = 0;
+  for (int s = s0; s < limit; ++s) {
+    edge_box_load(box, s);
+    const EdgeBoxRes* r = (const EdgeBoxRes*)g_dp;
+    ovf |= r->overflow; redo |= r->redo; cx |= r->complex;
+  }
+  LSYNC();
+  if (uni((int)ovf)) { X.overflow |= (uint32_t)uni((int)ovf); return 0; }
+  if (uni((int)redo)) {   // (a distance that is not a number, a candidate longer than a box sequence: in order, here)
+    edge_box_fold(box, first, s0);
+    return 0;
+  }
+  if (uni((int)cx)) X.complexRegion = true;
+  edge_box_fold(box, first, limit);
+  return 1;
+}
+
+// a claimed anchor of another wave's edge search, run here: `old` is what the claim's decrement returned
+TALC_DNC void edge_task_run(uint32_t victim_, int old_) {
+  PROF_DECL2;
+  PROF_BEGIN2();
+  const int l = lane_id();
+  const int old = uni(old_);
+  agent_fence();
+  uint8_t* box = uni_ptr(edge_box((uint32_t)uni((int)victim_)));
+  uint32_t* box32 = (uint32_t*)box;
+  const int limit = edge_ctx_load(box), s = limit - old;
+  X.headCov = nullptr;
+  X.cells = 0; X.steps = 0; X.overflow = 0; X.complexRegion = false;
+  X.nanSeen = 0u; X.nEdges = 0;
+  AnchorRec* mine = uni_ptr(X.dirRight ? X.ancL : X.ancR);
+  if (s >= 0 && s < limit && limit <= EDGE_BOX_ANCHORS) {
+    if (l < 6) ((uint32_t*)(mine + s))[l] = aload32(box32 + 24 + 6 * s + l);
+    WSYNC();
+    X.best2[0].have = false; X.best2[1].have = false;
+    edge_anchor_search_task(mine, s);
+    if (X.taskTest) X.nanSeen = 1u;
+    edge_box_store(box, s, X.complexRegion ? 1u : 0u);
+  }
+  agent_fence();
+  if (l == 0) (void)aadd32(box32 + offsetof(EdgeBoxHdr, done) / 4, 1u);
+  PROF_END2(PF_TRUN);
+}
+
+// a wave without a read looks for a published anchor; true: it has run one
+TALC_DNC bool edge_task_steal(int tries_) {
+  const int l = lane_id();
+  const int tries = uni(tries_);
+  const uint32_t nS = (uint32_t)uni((int)X.nSlots), me = (uint32_t)uni((int)X.mySlot);
+  {
+    int open = 0;
+    if (l == 0) open = (int)aload32(X.qwords + kQueueOpen);
+    if (uni(open) <= 0) return false;
+  }
+  // a window of 64 counters per try, a different one every time: with thousands of waves polling, every box is looked
+  // at within microseconds — and a wave between two reads spends one load on it (scanning all of avail[] from every idle
+  // wave was 7 TB/s of L2 traffic at the end of a launch)
+  const uint32_t nWin = (nS + 63u) >> 6;
+  for (int k = 0; k < tries; ++k) {
+    X.stealSeq += 1u;
+    const uint32_t win = (me * 2654435761u + X.stealSeq * 40503u) % nWin;
+    const uint32_t i = win * 64u + (uint32_t)l;
+    const int v = (i < nS && i != me) ? (int)aload32(X.avail + i) : 0;
+    unsigned long long m = ballot64(v > 0);
+    while (m != 0ull) {
+      const int src = (int)__builtin_ctzll(m);
+      m &= m - 1ull;
+      const uint32_t victim = (uint32_t)__shfl((int)i, src);
+      int old = 0;
+      if (l == 0) old = (int)aadd32(X.avail + victim, 0xFFFFFFFFu);
+      old = uni(old);
+      if (old > 0) {
+        if (l == 0) (void)aadd32(X.qwords + kQueueOpen, 0xFFFFFFFFu);
+        edge_task_run(victim, old);
+        return true;
+      }
+    }
+  }
+  return false;
+}
+
+// between two reads of a wave: the read it had is finished (whichever way it left the loop's body), and published anchors
+// — searches on the launch's critical path — come before a new read
+TALC_DNC void edge_between_reads() {
+  if (!X.holding) { X.holding = 1u; return; }
+  if (lane_id() == 0) (void)aadd32(X.qwords + kQueueFinished, 1u);
+  while (edge_task_steal(1)) { X.moreCells += X.cells; X.moreSteps += X.steps; }
+}
+// the end of a wave that has run out of reads; returns the 100 MHz ticks it slept (the profile build's utilisation figure)
+TALC_DNC unsigned long long edge_linger(uint32_t n_work_) {
+  const uint32_t n_work = (uint32_t)uni((int)n_work_);
+  const int l = lane_id();
+  unsigned long long idle = 0;
+  while (true) {
+    WSYNC();
+    if (edge_task_steal(8)) { X.moreCells += X.cells; X.moreSteps += X.steps; continue; }
+    uint32_t fin = 0;
+    if (l == 0) fin = aload32(X.qwords + kQueueFinished);
+    if ((uint32_t)uni((int)fin) >= n_work) break;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
+    idle += __builtin_amdgcn_s_memrealtime() - t0;
+  }
+  return idle;
+}
+
+TALC_DN bool search_edge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& weakUsed) {
+  const DevParams& P = X.P;
   const AnchorRec* anchors = uni_ptr(X.dirRight ? X.ancL : X.ancR);
   const int nAnch = uni(X.dirRight ? X.nAncL : X.nAncR);
   const int limit = min(nAnch, uni((int)P.MAX_START_ANCHORS));
-  const uint32_t readLen = (uint32_t)uni((int)X.L), maxInner = (uint32_t)uni((int)P.MAX_INNER_PATHS), CHECK = (uint32_t)uni((int)P.CHECK_INTERVAL);
-  X.best2[0].have = false; X.best2[1].have = false; X.nEdges = 0;
+  X.best2[0].have = false; X.best2[1].have = false; X.nEdges = 0; X.nanSeen = 0u;
+  bool mayPublish = (X.boxes != nullptr) && limit <= EDGE_BOX_ANCHORS && !X.tracing && X.weakLen >= X.taskMinWeak;
   for (int s = 0; s < limit; ++s) {
-    const AnchorRec a = uni_anchor(anchors + s);
-    const uint32_t whichStart = a.pos;
-    uint32_t stepCounter = 0;
-    int xdrop = (int)((double)(int)P.CHECK_INTERVAL * P.FAILURE_RATE + 1.0);   // :1031
-    // currentGap = extractWeakBorderSequence(seq, whichStart, K, location) (:1035)
-    uint32_t gapLen;
-    X.refLen = 0;
-    X.ref = X.refBuf;
-    if (X.dirRight) {   // TAIL: anchor + suffix(seq, whichStart+K): the read's own tail, read in place
-      gapLen = readLen - (whichStart + K);
-      X.ref = const_cast<uint8_t*>(X.read) + whichStart;
-      X.refLen = readLen - whichStart;
-    } else {            // HEAD: prefix(seq, whichStart) + anchor
-      gapLen = whichStart;
-      ref_append(whichStart, whichStart + K);
-      ref_append(0, whichStart);
+    if (uni((int)mayPublish) && limit - s >= 2 && ((X.weakLen >= X.taskHeavy && X.qi < X.heavyUpTo) || queue_is_dry())) {
+      const int folded = uni(edge_anchors_as_tasks(anchors, s, limit));
+      if (X.overflow) return false;
+      if (folded) break;
+      mayPublish = false;
     }
-    WSYNC();
-    const uint32_t PATH_MAXLENGTH = (uint32_t)(int)(1.2 * (double)gapLen + (double)(2 * K));
-    if (!pool_shape(PATH_MAXLENGTH)) return false;
-    PROF_BEGIN2(); init_first_trail(a, anchors + s, false, PATH_MAXLENGTH); PROF_END2(PF_INITTR);
-    int nCur = 1;
-    int len = (int)K;
-    while ((int)(nCur > 0) & (int)((uint32_t)nCur <= maxInner) & (int)((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH) & (int)(uni((int)X.overflow) == 0)) {
-      if (nCur == 1) {
-        PROF_BEGIN2();
-        const int ff = uni(fast_forward(len, stepCounter, PATH_MAXLENGTH, true));
-        len += ff;
-        PROF_END2(PF_FFWD);
-        if (ff > 0 && ((uint32_t)uni((int)stepCounter) % CHECK == 0)) {
-          // the fast-forward took the step after which scoring is due (Explorer.cpp:672-686): the one Trail stays
-          // where it is (set ia, slot 0) — score it there; five or fewer survivors means no gardening
-          PROF_BEGIN2();
-          nCur = uni(score_edges(X.ia, 1, len, xdrop));
-          PROF_END2(PF_STEPE);
-          continue;
-        }
-        if (!((uint32_t)uni((int)stepCounter) < PATH_MAXLENGTH)) break;
-      }
-      PROF_BEGIN2();
-      nCur = uni(step_edge(nCur, len, stepCounter, PATH_MAXLENGTH, xdrop));
-      PROF_END2(PF_STEPE);
-      ++len;
-      if (uni((int)(X.traceSteps)))
-        trace_rec(TR_STEP, (int)stepCounter, nCur, X.nEdges, xdrop, 0.0, nullptr, 0, false);
-    }
+    edge_anchor_search(anchors, s);
     if (X.overflow) return false;
   }
   bool found = false;
@@ -3313,7 +3673,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
          uint8_t* __restrict__ outAll,
          const uint64_t* __restrict__ outoff, const uint32_t* __restrict__ order, uint32_t n_work,
          uint32_t* __restrict__ queue, uint8_t* __restrict__ scratchAll, uint64_t* __restrict__ counters, TraceBuf trace,
-         uint32_t traceRead, uint32_t launchStamp, uint32_t flags) {
+         uint32_t traceRead, uint32_t launchStamp, uint32_t flags, EdgeTaskArgs E) {
   __shared__ uint32_t s_next;
   const int l = lane_id();
   uint8_t* slot = scratchAll + (uint64_t)blockIdx.x * C.slotBytes;
@@ -3332,6 +3692,14 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.launchStamp = launchStamp;
   X.noForkStep = (flags >> 1) & 1u;
   X.childrenByLane = ((flags >> 2) & 1u) ^ 1u;
+  // (over a graph that does not branch the queue's order alone keeps the waves busy 95 % of the launch, and the tasks'
+  //  bookkeeping and the waves that stay cost config 2 0.7 %: the batch's fork share decides, k_order_scale)
+  if (E.boxes != nullptr && E.autoSwitch != nullptr && *E.autoSwitch == 0u) E.boxes = nullptr;
+  X.boxes = E.boxes; X.avail = E.avail; X.qwords = queue; X.boxSeqCap = E.seqCap; X.boxBytes = (uint32_t)edge_box_bytes(E.seqCap);
+  X.nSlots = gridDim.x; X.mySlot = blockIdx.x; X.nWork = n_work; X.taskMinWeak = E.minWeak; X.nanSeen = 0u; X.taskTest = E.test;
+  X.taskHeavy = E.heavy; X.heavyUpTo = (E.heavyRounds >= 0xFFFFu) ? 0xFFFFFFFFu : E.heavyRounds * gridDim.x;
+  X.qi = 0; X.holding = 0u; X.stealSeq = 0u; X.moreCells = 0; X.moreSteps = 0;
+  const uint32_t lingerMod = max(E.lingerMod, 1u);   // (5120 waves polling two words kept a memory channel busy: config 2 + 0.7 ms with nothing ever published)
   X.searchNo = 16u;   // (stamps below 16 << 12 could be matrix values)
   {
     uint8_t* g = slot + C.o_gard;
@@ -3352,16 +3720,12 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   if (l == 0) { for (int i = 0; i < PF_N; ++i) g_prof[i] = 0; for (int i = 0; i < 4; ++i) g_wprof[i] = 0; }
   const unsigned long long _pf_k0 = __builtin_amdgcn_s_memtime();
   const unsigned long long _pf_r0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
-  unsigned long long _pf_rd0 = 0;
+  unsigned long long _pf_rd0 = 0, _pf_idle = 0;   // (_pf_idle: asleep without a read, waiting for anchors to be published)
   uint32_t _pf_prevQi = 0, _pf_prevR = 0;
 #endif
 
   while (true) {
     WSYNC();
-    if (l == 0) s_next = atomicAdd(queue, 1u);
-    WSYNC();
-    const uint32_t qi = s_next;
-    if (qi >= n_work) break;
 #ifdef TALC_PROF
     if (l == 0 && _pf_rd0) {   // duration of the previous read of this wave (100 MHz ticks)
       const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - _pf_rd0;
@@ -3369,11 +3733,23 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       g_prof[PF_RD0 + bk] += 1;
       if (dt > g_prof[PF_RDMAX]) g_prof[PF_RDMAX] = (uint32_t)dt;
       state[_pf_prevR].pfTicks = (uint32_t)dt;
+      _pf_rd0 = 0;
     }
+#endif
+    if (X.boxes != nullptr) edge_between_reads();
+    if (l == 0) s_next = atomicAdd(queue, 1u);
+    WSYNC();
+    const uint32_t qi = s_next;
+    if (qi >= n_work) break;
+    X.qi = qi;
+#ifdef TALC_PROF
     _pf_rd0 = __builtin_amdgcn_s_memrealtime();
 #endif
     PROF_BEGIN2();
     const uint32_t r = order[qi];
+#ifdef TALC_PROF
+    if (l == 0) state[r].pfStart = (uint32_t)_pf_rd0;
+#endif
 #ifdef TALC_PROF
     _pf_prevQi = qi; _pf_prevR = r;
 #endif
@@ -3405,6 +3781,9 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     }
     WSYNC();
     uint32_t weakUsed = 0;
+#ifdef TALC_PROF
+    uint32_t _pf_edge = 0; unsigned long long _pf_e0 = 0; (void)_pf_e0;
+#endif
     PROF_END2(PF_PROLOG);
     // head / tail presence as set by setInitialStructure (Read.cpp:223-237)
     bool headPresent = false, tailPresent = false;
@@ -3449,7 +3828,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         X.nAncL = 0;
         build_anchors(1);
         if (uni((int)X.tracing)) trace_search_cold();
-        PROF_BEGIN2(); headCorr = search_edge(headOff, headCLen, weakUsed); PROF_END2(PF_SRCHE);
+        PROF_BEGIN2(); PF_EDGE_T0(); headCorr = search_edge(headOff, headCLen, weakUsed); PF_EDGE_T1(); PROF_END2(PF_SRCHE);
         if (uni((int)X.tracing)) {
           if (headCorr) trace_rec(TR_RESULT, 0, 1, 0, (int)X.Rs, 0.0, X.weak + headOff, headCLen, false);
           else trace_rec(TR_RESULT, 0, 0, 0, (int)X.regS[0], 0.0, X.read, X.weakLen, false);
@@ -3466,7 +3845,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         X.nAncR = 0;
         build_anchors(0);
         if (uni((int)X.tracing)) trace_search_cold();
-        PROF_BEGIN2(); tailCorr = search_edge(tailOff, tailCLen, weakUsed); PROF_END2(PF_SRCHE);
+        PROF_BEGIN2(); PF_EDGE_T0(); tailCorr = search_edge(tailOff, tailCLen, weakUsed); PF_EDGE_T1(); PROF_END2(PF_SRCHE);
         if (uni((int)X.tracing)) {
           if (tailCorr) trace_rec(TR_RESULT, 2, 1, (int)X.Le, 0, 0.0, X.weak + tailOff, tailCLen, false);
           else trace_rec(TR_RESULT, 2, 0, (int)X.regE[R - 1], 0, 0.0, X.read + X.regE[R - 1] + K, X.weakLen, false);
@@ -3478,7 +3857,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     }
     totCells += X.cells; totSteps += X.steps;
 #ifdef TALC_PROF
-    if (l == 0) state[r].pfSteps = (uint32_t)X.steps;
+    if (l == 0) { state[r].pfSteps = (uint32_t)X.steps; state[r].pfEdgeTicks = _pf_edge; state[r].pfAnchors = g_prof[PF_RANCH]; state[r].pfAnchorMax = g_prof[PF_RANCHMAX]; g_prof[PF_RANCH] = 0; g_prof[PF_RANCHMAX] = 0; }
 #endif
     if (X.overflow) {
       copy_bytes(out, X.read, L, false);
@@ -3533,6 +3912,17 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     }
     PROF_END2(PF_ASSEMBLE);
   }
+  // no reads left: run published anchors of the edge searches still going on, until every read is finished
+#ifdef TALC_PROF
+  if (l == 0) atomicMin((unsigned long long*)&counters[124], __builtin_amdgcn_s_memrealtime());   // the first wave to find the queue dry
+#endif
+  if (X.boxes != nullptr && blockIdx.x % lingerMod == 0u) {
+#ifdef TALC_PROF
+    _pf_idle =
+#endif
+    edge_linger(n_work);
+  }
+  totCells += X.moreCells; totSteps += X.moreSteps;
   if (l == 0) {
     if (totSteps) atomicAdd((unsigned long long*)&counters[0], totSteps);
     if (totCells) atomicAdd((unsigned long long*)&counters[1], totCells);
@@ -3541,7 +3931,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     g_prof[PF_XSTAGE] = g_wprof[0]; g_prof[PF_XLEV] = g_wprof[1]; g_prof[PF_XSEL] = g_wprof[2]; g_prof[PF_XNLEV] = g_wprof[3];
     {   // wave utilisation of the launch: sum of the waves' lifetimes against (last end - first start) x waves
       const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-      atomicAdd((unsigned long long*)&counters[125], r1 - _pf_r0);   // (counters[2 .. 2 + PF_N) are the categories)
+      atomicAdd((unsigned long long*)&counters[125], r1 - _pf_r0 - _pf_idle);   // (counters[2 .. 2 + PF_N) are the categories)
       atomicMin((unsigned long long*)&counters[126], _pf_r0);
       atomicMax((unsigned long long*)&counters[127], r1);
       // the wave's last read: (queue position, read), (its start, the wave's end) — TALC_PROF_SLOW prints the waves that end last
@@ -3550,7 +3940,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
         counters[128 + 2 * blockIdx.x] = ((unsigned long long)_pf_prevQi << 32) | _pf_prevR;
         counters[129 + 2 * blockIdx.x] = ((_pf_rd0 & 0xFFFFFFFFull) << 32) | (r1 & 0xFFFFFFFFull);
       }
-      static_assert(2 + PF_N <= 125, "the profile categories run into the utilisation counters");
+      static_assert(2 + PF_N <= 124, "the profile categories run into the utilisation counters");
     }
     for (int i = 0; i < PF_N; ++i) {
       if (i == PF_RDMAX) atomicMax((unsigned long long*)&counters[2 + i], (unsigned long long)g_prof[i]);
@@ -3563,16 +3953,34 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
 // ==================================================================== work-queue order
 // Reads by descending cost estimate, without a sort: a 1024-bucket counting sort on a 10-bit logarithmic key (the order
 // inside a bucket is whatever the atomics make it: records do not depend on the order reads are taken in).
-TALC_D uint32_t order_bucket(const ReadState& st) {
+// The key: the estimate, with its inner-gap part weighed by `gapScale` (in 1/256).  Over a branching graph (paralog
+// families: 3.5 % of the solid k-mers of a batch fork, against 1 % over unique sequence with sequencing-error k-mers) a base
+// of an inner gap costs ten to twenty times what it costs elsewhere — the walk carries several Trails — while the edges
+// cost the same, and the edges are the part of a read other waves can take over (edge tasks): the reads with long inner
+// gaps have to start first there.  k_order_scale: 1 up to a fork share of 1.2 %, + 1 per further 1 %, at most 3.
+TALC_D uint32_t order_bucket(const ReadState& st, uint32_t gapScale) {
   if (st.status != TALC_READ_CORRECTED || st.overflow) return 1023u;   // passed through: last
-  const uint32_t c = st.costEst | 1u;
+  const unsigned long long key = (unsigned long long)st.costEst + (((unsigned long long)st.costGap * (gapScale - 256u)) >> 8);
+  const uint32_t c = (uint32_t)min(key, 0xFFFFFFFFull) | 1u;
   const int e = 31 - __builtin_clz(c);                               // 0..31
   const uint32_t m = (e >= 5) ? ((c >> (e - 5)) & 31u) : ((c << (5 - e)) & 31u);
   return 1022u - min(1022u, (uint32_t)e * 32u + m);                  // heavy first
 }
-__global__ void k_order_hist(const ReadState* __restrict__ state, uint32_t n, uint32_t* __restrict__ hist) {
+__global__ void __launch_bounds__(64) k_order_scale(uint32_t* __restrict__ batchStats, uint32_t fixedScale) {   // batchStats[128] := the gap scale, [129] := the graph branches
+  const int l = lane_id();
+  const unsigned long long fork = wave_sum_u64(batchStats[2 * l]), solid = wave_sum_u64(batchStats[2 * l + 1]);
+  uint32_t scale = 256u;
+  if (solid > 0) {
+    const unsigned long long perMille10 = fork * 10000ull / solid;   // fork share in 1/10000
+    if (perMille10 > 120ull) scale = 256u + (uint32_t)min((perMille10 - 120ull) * 256ull / 100ull, 512ull);
+  }
+  if (l == 0) batchStats[129] = scale > 256u ? 1u : 0u;   // (the edge tasks' switch)
+  if (fixedScale) scale = fixedScale;
+  if (l == 0) batchStats[128] = scale;
+}
+__global__ void k_order_hist(const ReadState* __restrict__ state, uint32_t n, uint32_t* __restrict__ hist, const uint32_t* __restrict__ batchStats) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) atomicAdd(&hist[order_bucket(state[r])], 1u);
+  if (r < n) atomicAdd(&hist[order_bucket(state[r], batchStats[128])], 1u);
 }
 __global__ void __launch_bounds__(1024) k_order_scan(uint32_t* __restrict__ hist) {   // hist[b] := first position of bucket b
   __shared__ uint32_t s[1024];
@@ -3588,9 +3996,10 @@ __global__ void __launch_bounds__(1024) k_order_scan(uint32_t* __restrict__ hist
   }
   hist[t] = s[t] - v;
 }
-__global__ void k_order_scatter(const ReadState* __restrict__ state, uint32_t n, uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
+__global__ void k_order_scatter(const ReadState* __restrict__ state, uint32_t n, uint32_t* __restrict__ cursor, uint32_t* __restrict__ order,
+                                const uint32_t* __restrict__ batchStats) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) order[atomicAdd(&cursor[order_bucket(state[r])], 1u)] = r;
+  if (r < n) order[atomicAdd(&cursor[order_bucket(state[r], batchStats[128])], 1u)] = r;
 }
 
 // ==================================================================== the count model's thresholds (DevParams.thr)

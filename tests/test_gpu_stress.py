@@ -36,6 +36,31 @@ def test_stress_draw_matches_oracle(case, n_reads):
     assert int(np.bincount(ost, minlength=4)[0]) > 0.85 * n_reads         # the draw really is corrected reads
 
 
+def test_edge_anchors_run_by_other_waves_match_oracle(monkeypatch):
+    """The start anchors of a head / tail search handed to waves that have run out of reads (talc_kernels_search.h, "edge
+    tasks"): 1200 reads over a branching graph (set 102, K = 25) with every edge published from the start of its search,
+    with the in-order redo forced for every anchor another wave has run, with the default thresholds, as the batch itself
+    decides, with the tasks off, with few wave slots (the queue runs dry while most reads are still in their inner gaps)
+    and every wave staying to the end, and with the first round's rule alone — each against the oracle's records."""
+    pair, kw = _pair(102)
+    bases, offs = pair.reads(0, 1200)
+    o_out, o_off, o_st = pair.otab.correct_batch(bases, offs, nthreads=16)
+    so = PU.seqs_of(o_out, o_off)
+    on = {"TALC_EDGE_TASKS": "1"}
+    for env in (dict(on, TALC_EDGE_TASK_MIN="0", TALC_EDGE_TASK_HEAVY="0"), dict(on, TALC_EDGE_TASK_MIN="0", TALC_TEST_EDGE_REDO="1"),
+                on, {}, {"TALC_EDGE_TASKS": "0"}, dict(on, TALC_EDGE_TASK_MIN="0", TALC_SEARCH_SLOTS="700", TALC_EDGE_LINGER_MOD="1"),
+                dict(on, TALC_EDGE_TASK_ROUNDS="1", TALC_EDGE_TASK_HEAVY="100")):
+        for k in ("TALC_EDGE_TASKS", "TALC_EDGE_TASK_MIN", "TALC_EDGE_TASK_HEAVY", "TALC_EDGE_TASK_ROUNDS", "TALC_TEST_EDGE_REDO",
+                  "TALC_SEARCH_SLOTS", "TALC_EDGE_LINGER_MOD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g_out, g_off, g_st = pair.ctx.correct(bases, offs)
+        sg = PU.seqs_of(g_out, g_off)
+        bad = [i for i in range(len(so)) if so[i] != sg[i] or int(o_st[i]) != int(g_st[i])]
+        assert not bad, (env, bad[:5])
+
+
 def test_half_corrected_reads_over_a_branching_graph_match_oracle():
     """100 reads of set 101, every second one replaced by its own corrected form: nearly clean reads over a branching
     graph (anchor lists of a whole kilobase region, Explorer.cpp:493-543; x-drops of several hundred)."""
