@@ -49,8 +49,8 @@ if has configs; then
   done
 fi
 if has prof; then
-  TALC_PROF_PRINT=1 TALC_LIB=talc_amd/_build/libtalc_hip_prof.so timeout -k 10 300 python3 tools/search_bench.py --reps 1 --no-paralog 2>&1 | grep "^\[prof\]" | awk '{k=$2" "$3} !seen[k]++' | tail -75 > $DST/${TAG}_category_profile_config2.txt
-  TALC_PROF_PRINT=1 TALC_LIB=talc_amd/_build/libtalc_hip_prof.so timeout -k 10 300 python3 tools/search_bench.py --reps 1 --no-main 2>&1 | grep "^\[prof\]" | tail -75 > $DST/${TAG}_category_profile_paralog.txt
+  TALC_PROF_PRINT=1 TALC_LIB=talc_amd/_build/libtalc_hip_prof.so timeout -k 10 300 python3 tools/search_bench.py --reps 1 --no-paralog 2>&1 | grep "^\[prof\]" | awk '{k=$2" "$3} !seen[k]++' | tail -95 > $DST/${TAG}_category_profile_config2.txt
+  TALC_PROF_PRINT=1 TALC_LIB=talc_amd/_build/libtalc_hip_prof.so timeout -k 10 300 python3 tools/search_bench.py --reps 1 --no-main 2>&1 | grep "^\[prof\]" | tail -95 > $DST/${TAG}_category_profile_paralog.txt
   echo "[collect] category profiles done"
 fi
 if has rehearse; then

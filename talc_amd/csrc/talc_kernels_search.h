@@ -3720,7 +3720,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   if (l == 0) { for (int i = 0; i < PF_N; ++i) g_prof[i] = 0; for (int i = 0; i < 4; ++i) g_wprof[i] = 0; }
   const unsigned long long _pf_k0 = __builtin_amdgcn_s_memtime();
   const unsigned long long _pf_r0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
-  unsigned long long _pf_rd0 = 0, _pf_idle = 0;   // (_pf_idle: asleep without a read, waiting for anchors to be published)
+  unsigned long long _pf_rd0 = 0, _pf_lastStart = 0, _pf_loopEnd = 0, _pf_idle = 0;   // (_pf_idle: asleep without a read, waiting for anchors to be published)
   uint32_t _pf_prevQi = 0, _pf_prevR = 0;
 #endif
 
@@ -3733,7 +3733,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       g_prof[PF_RD0 + bk] += 1;
       if (dt > g_prof[PF_RDMAX]) g_prof[PF_RDMAX] = (uint32_t)dt;
       state[_pf_prevR].pfTicks = (uint32_t)dt;
-      _pf_rd0 = 0;
+      _pf_lastStart = _pf_rd0; _pf_rd0 = 0;
     }
 #endif
     if (X.boxes != nullptr) edge_between_reads();
@@ -3914,7 +3914,8 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   }
   // no reads left: run published anchors of the edge searches still going on, until every read is finished
 #ifdef TALC_PROF
-  if (l == 0) atomicMin((unsigned long long*)&counters[124], __builtin_amdgcn_s_memrealtime());   // the first wave to find the queue dry
+  _pf_loopEnd = __builtin_amdgcn_s_memrealtime();
+  if (l == 0) atomicMin((unsigned long long*)&counters[124], _pf_loopEnd);   // the first wave to find the queue dry
 #endif
   if (X.boxes != nullptr && blockIdx.x % lingerMod == 0u) {
 #ifdef TALC_PROF
@@ -3938,7 +3939,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
       if (_pf_rd0) state[_pf_prevR].pfTicks = (uint32_t)(r1 - _pf_rd0);
       if (blockIdx.x < 8192u) {
         counters[128 + 2 * blockIdx.x] = ((unsigned long long)_pf_prevQi << 32) | _pf_prevR;
-        counters[129 + 2 * blockIdx.x] = ((_pf_rd0 & 0xFFFFFFFFull) << 32) | (r1 & 0xFFFFFFFFull);
+        counters[129 + 2 * blockIdx.x] = ((_pf_lastStart & 0xFFFFFFFFull) << 32) | (_pf_loopEnd & 0xFFFFFFFFull);   // (the end of its last read, not of its stay)
       }
       static_assert(2 + PF_N <= 124, "the profile categories run into the utilisation counters");
     }
