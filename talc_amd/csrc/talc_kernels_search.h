@@ -49,6 +49,7 @@ struct ReadState {
   // profile build only (TALC_PROF_READS=file writes one row per read): the estimate's inputs and what the search took
   uint32_t pfHead, pfTail, pfGapSum, pfFork, pfSolid, pfTicks;   // pfTicks: 100 MHz
   uint32_t pfGapSq, pfGapMax, pfShortReg, pfSteps;
+  uint32_t pfBridges, pfBridgeMax;   // start anchors of bridge searches walked, the longest walk (100 MHz)
   uint32_t pfEdgeTicks, pfAnchors, pfAnchorMax, pfStart;   // (pfStart: low 32 bits of the 100 MHz counter when the search took the read)   // 100 MHz ticks inside search_edge; edge anchors searched by this wave, the longest
 #endif
 };
@@ -92,7 +93,7 @@ struct SearchCaps : SearchLimits {
 #ifndef ROW_ARENA_INTS
 #define ROW_ARENA_INTS (448 * 1024)
 #endif
-#define ROW_MAX_REF 2047
+#define ROW_MAX_REF 4095
 #define WIDE_BLOOM_WORDS 16384
 #ifndef WIDE_BLOOM_MIN_PATH
 #define WIDE_BLOOM_MIN_PATH 600   /* Trails that may grow beyond this many bases use it (config 5: search 122 / 113 / 107 / 104 / 103 / 104 ms at 2500 / 1500 / 1000 / 700 / 450 / 300) */
@@ -674,7 +675,7 @@ enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN
        PF_EDGEMISC, PF_ANCHORS, PF_ASSEMBLE, PF_STEPB, PF_STEPE, PF_SRCHB, PF_SRCHE, PF_PROLOG, PF_INITTR, PF_TOTAL, PF_NCALLS, PF_NSTEPS,
        PF_FFLOAD, PF_FFREC, PF_FFFLUSH, PF_FFENTRY, PF_NRECS, PF_RD0, PF_RD1, PF_RD2, PF_RD3, PF_RD4, PF_RD5, PF_RDMAX,
        PF_XSTAGE, PF_XLEV, PF_XSEL, PF_REFB, PF_RESULT, PF_CYQ, PF_CYX, PF_CYHIT, PF_CYFILL,
-       PF_SB11, PF_SB12, PF_SB21, PF_SB10, PF_SBOTHER, PF_SEGEN, PF_XCALLS, PF_XNLEV, PF_FSFORK, PF_FSDEAD, PF_FSFILT, PF_FSLIM, PF_FK1, PF_FK2, PF_FKBAIL, PF_FORK, PF_ANCCALLS, PF_ANCITER, PF_TPUB, PF_TOWN, PF_TSTOLEN, PF_TWAIT, PF_TRUN, PF_EA0, PF_EA1, PF_EA2, PF_EA3, PF_EA4, PF_EASUM3, PF_EASUM4, PF_RANCH, PF_RANCHMAX, PF_N };
+       PF_SB11, PF_SB12, PF_SB21, PF_SB10, PF_SBOTHER, PF_SEGEN, PF_XCALLS, PF_XNLEV, PF_FSFORK, PF_FSDEAD, PF_FSFILT, PF_FSLIM, PF_FK1, PF_FK2, PF_FKBAIL, PF_FORK, PF_ANCCALLS, PF_ANCITER, PF_TPUB, PF_TOWN, PF_TSTOLEN, PF_TWAIT, PF_TRUN, PF_EA0, PF_EA1, PF_EA2, PF_EA3, PF_EA4, PF_EASUM3, PF_EASUM4, PF_RANCH, PF_RANCHMAX, PF_RBR, PF_RBRMAX, PF_N };
 #define TALC_PF_NAMES {"probe", "child", "aims", "cycle", "ffwd", "scorebr", "garden", "evalfull", "xdrop", "extnw", "edgemisc", \
                        "anchors", "assemble", "stepb*", "stepe*", "srchb*", "srche*", "prolog", "inittr", "total", "#ffcalls", "#ffsteps", \
                        "ff.load", "ff.record", "ff.flush", "ff.entry", "#ffrecords", "#reads<0.25ms", "#reads<1ms", "#reads<4ms", \
@@ -683,7 +684,7 @@ enum { PF_PROBE = 0, PF_CHILD, PF_AIMS, PF_CYCLE, PF_FFWD, PF_SCOREBR, PF_GARDEN
                        "#stepb 1->1", "#stepb 1->2", "#stepb 2->1", "#stepb 1->0", "#stepb other", "#stepe generic", "#xdrop calls", "#xdrop levels", \
                        "#ffstop fork", "#ffstop deadend", "#ffstop filter", "#ffstop limit/other", "#forkstep 1 child", "#forkstep fork+deadend", "#forkstep bailed", "forkstep", "#anchor lists", "#anchor level tests", \
                        "#edges published", "#anchors by owner", "#anchors by others", "t.owner waits", "t.run by others", \
-                       "#edge anchors<1ms", "#edge anchors<4ms", "#edge anchors<16ms", "#edge anchors<64ms", "#edge anchors>=64ms", "ticks anchors 16-64ms", "ticks anchors>=64ms", "(per read) anchors", "(per read) longest anchor"}
+                       "#edge anchors<1ms", "#edge anchors<4ms", "#edge anchors<16ms", "#edge anchors<64ms", "#edge anchors>=64ms", "ticks anchors 16-64ms", "ticks anchors>=64ms", "(per read) anchors", "(per read) longest anchor", "(per read) bridge attempts", "(per read) longest bridge attempt"}
 
 struct Wv {
   // kernel constants
@@ -1979,7 +1980,7 @@ TALC_DNC void score_bridges_rows(int ib_, int nNew_, int m_, int tlen_, uint32_t
   X.cells += ncells;
   WSYNC();
 }
-static_assert(ROW_MAX_REF <= 64 * 32 - 1, "the widest instance takes 32 columns per lane");
+static_assert(ROW_MAX_REF <= 64 * 64 - 1, "the widest instance takes 64 columns per lane");
 
 TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_) {
   const DevParams& P = X.P;
@@ -1997,7 +1998,12 @@ TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_)
   else if (B <= 12) score_bridges_rows<12>(ib, nNew, len + 1, tlen, rowAvail);
   else if (B <= 16) score_bridges_rows<16>(ib, nNew, len + 1, tlen, rowAvail);
   else if (B <= 24) score_bridges_rows<24>(ib, nNew, len + 1, tlen, rowAvail);
-  else score_bridges_rows<32>(ib, nNew, len + 1, tlen, rowAvail);
+  else if (B <= 32) score_bridges_rows<32>(ib, nNew, len + 1, tlen, rowAvail);
+  // (references of 2048-4095 bases: the row no longer fits the registers and these two instances spill — still a thousand
+  //  times less work than aligning every Trail of a 2 kb gap from scratch at every scoring, which is what made ONE walk of
+  //  stress set 105 take 40 s)
+  else if (B <= 48) score_bridges_rows<48>(ib, nNew, len + 1, tlen, rowAvail);
+  else score_bridges_rows<64>(ib, nNew, len + 1, tlen, rowAvail);
 }
 
 // A child of the generic step whose tip is an aim (checkAims, Trail.cpp:273-285): recordBridge (Explorer.cpp:1097-1101).
@@ -3081,6 +3087,9 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
     LSYNC();
   }
   for (int s = 0; s < limit && !found; ++s) {
+#ifdef TALC_PROF
+    const unsigned long long _pf_b0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const AnchorRec a = uni_anchor(anchors + s);
     const uint32_t whichStart = a.pos;
     const uint32_t Rs = (uint32_t)uni((int)X.Rs), Re = (uint32_t)uni((int)X.Re), Ls = (uint32_t)uni((int)X.Ls), Le = (uint32_t)uni((int)X.Le);
@@ -3132,6 +3141,12 @@ TALC_D bool search_bridge(uint32_t& weakOutOff, uint32_t& weakOutLen, uint32_t& 
       ++len;
       if (uni((int)(X.traceSteps))) trace_rec(TR_STEP, (int)stepCounter, nCur, X.nFull, 0, 0.0, nullptr, 0, false);
     }
+#ifdef TALC_PROF
+    if (l == 0) {   // (the walk of this start anchor, without the evaluation of what it recorded)
+      const uint32_t dt = (uint32_t)(__builtin_amdgcn_s_memrealtime() - _pf_b0);
+      g_prof[PF_RBR] += 1; if (dt > g_prof[PF_RBRMAX]) g_prof[PF_RBRMAX] = dt;
+    }
+#endif
     if (X.overflow) return false;
     if (X.nFull > 0) {
       // :945-960 score every recorded bridge, cut its anchors; quirk :955-960 keeps the FIRST nOK
@@ -3857,7 +3872,8 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
     }
     totCells += X.cells; totSteps += X.steps;
 #ifdef TALC_PROF
-    if (l == 0) { state[r].pfSteps = (uint32_t)X.steps; state[r].pfEdgeTicks = _pf_edge; state[r].pfAnchors = g_prof[PF_RANCH]; state[r].pfAnchorMax = g_prof[PF_RANCHMAX]; g_prof[PF_RANCH] = 0; g_prof[PF_RANCHMAX] = 0; }
+    if (l == 0) { state[r].pfSteps = (uint32_t)X.steps; state[r].pfEdgeTicks = _pf_edge; state[r].pfAnchors = g_prof[PF_RANCH]; state[r].pfAnchorMax = g_prof[PF_RANCHMAX]; g_prof[PF_RANCH] = 0; g_prof[PF_RANCHMAX] = 0;
+                  state[r].pfBridges = g_prof[PF_RBR]; state[r].pfBridgeMax = g_prof[PF_RBRMAX]; g_prof[PF_RBR] = 0; g_prof[PF_RBRMAX] = 0; }
 #endif
     if (X.overflow) {
       copy_bytes(out, X.read, L, false);
@@ -4106,7 +4122,9 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
       else if (B <= 12) sc = wave_nw_rows<12>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
       else if (B <= 16) sc = wave_nw_rows<16>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
       else if (B <= 24) sc = wave_nw_rows<24>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
-      else sc = wave_nw_rows<32>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 32) sc = wave_nw_rows<32>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 48) sc = wave_nw_rows<48>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else sc = wave_nw_rows<64>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
       i0 = m;
       WSYNC();
       const int ex = nw_score(a, tlen, b, m, 4, -3, -2, true);
