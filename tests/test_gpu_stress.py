@@ -61,6 +61,17 @@ def test_edge_anchors_run_by_other_waves_match_oracle(monkeypatch):
         assert not bad, (env, bad[:5])
 
 
+def test_gaps_beyond_2047_bases_over_a_branching_graph_match_oracle():
+    """300 reads of set 105 (K = 31, 40 % paralogs, reads to 20 kb): inner gaps of 2-3 kb walked with several Trails, whose
+    scoreBridges alignments are continued in the kept rows' two widest instances (references of 2048-4095 bases) — the walks
+    that took tens of seconds of one wave while every Trail was aligned from scratch."""
+    pair, kw = _pair(105)
+    bases, offs = pair.reads(0, 300)
+    bad, (so, ost), _ = PU.compare_correction(pair, bases, offs, nthreads=16, verbose=False)
+    assert not bad, bad[:5]
+    assert max(len(q) for q in so) > 10_000 and pair.last_times[1] < 8.0   # (the HIP path with its first allocations: under a second; 14 s before the wide rows)
+
+
 def test_half_corrected_reads_over_a_branching_graph_match_oracle():
     """100 reads of set 101, every second one replaced by its own corrected form: nearly clean reads over a branching
     graph (anchor lists of a whole kilobase region, Explorer.cpp:493-543; x-drops of several hundred)."""
