@@ -736,7 +736,7 @@ struct Wv {
   // edge tasks (the start anchors of a head / tail search handed to waves that have run out of reads; nullptr: none)
   uint8_t* boxes; uint32_t* avail; uint32_t* qwords;
   uint32_t boxBytes, boxSeqCap, nSlots, mySlot, nWork, taskMinWeak;
-  uint32_t taskHeavy;              // a border of at least this many bases is published when its search starts (reads of the queue's first round)
+  uint32_t taskHeavy;              // a border of at least this many bases is published when its search starts (queue positions below heavyUpTo)
   uint32_t qi, heavyUpTo;          // the current read's position in the work queue; `taskHeavy` applies below this position
   uint32_t holding;                // this wave has had a read (the one before the read it takes now is finished)
   uint32_t stealSeq;               // calls of edge_task_steal (which window of avail[] the next one looks at)
@@ -3332,10 +3332,12 @@ TALC_DN void edge_anchor_search_task(const AnchorRec* anchors, int s) { edge_anc
 // sortOutBestBorder keeps the FIRST best by (score, distance) — a fold, so the best of every anchor, merged in anchor order
 // under the same strict comparison, is the sequential result (m_complexRegion is an OR).  A read with a 500-base head
 // and tail is ten such searches and, over a branching graph, a tenth of a second of ONE wave: the launch ended when the
-// heaviest of them did, with two thirds of the waves idle.  So: once the work queue has run dry, a wave about to start
-// an anchor publishes the anchors its search still has to do in its box (one per wave slot, in HBM), waves without a
-// read claim them one at a time, run them in their own scratch and write the anchor's best long / best short candidate
-// back; the owner claims from the same counter, waits for the claimed ones, and merges in anchor order.
+// heaviest of them did, with two thirds of the waves idle.  So: a wave about to start an anchor publishes the anchors its
+// search still has to do in its box (one per wave slot, in HBM) — from the search's start for a long border (taskHeavy;
+// its anchors take tens of milliseconds each), otherwise once the work queue has run dry (taskMinWeak) —, waves between
+// two reads and the waves that stay when the reads are gone claim them one at a time, run them in their own scratch and
+// write the anchor's best long / best short candidate back; the owner claims from the same counter, waits for the
+// claimed ones, and merges in anchor order.  (What did not work on the way to this form: docs/results_log_r04.md.)
 //   avail[slot]   unclaimed anchors of the slot's box (claim = atomic decrement; the claimed anchor is limit - old value)
 //   hdr.done      anchors finished (owner waits for claimed == done)
 //   qwords[256]   reads finished (a wave without a read leaves when this reaches n_work: nothing can be published any more)
@@ -3603,7 +3605,7 @@ TALC_DNC bool edge_task_steal(int tries_) {
 }
 
 // between two reads of a wave: the read it had is finished (whichever way it left the loop's body), and published anchors
-// — searches on the launch's critical path — come before a new read
+// — long borders of reads already under way — come before a new read
 TALC_DNC void edge_between_reads() {
   if (!X.holding) { X.holding = 1u; return; }
   if (lane_id() == 0) (void)aadd32(X.qwords + kQueueFinished, 1u);
