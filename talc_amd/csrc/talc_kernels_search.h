@@ -93,7 +93,8 @@ struct SearchCaps : SearchLimits {
 #ifndef ROW_ARENA_INTS
 #define ROW_ARENA_INTS (448 * 1024)
 #endif
-#define ROW_MAX_REF 4095
+#define ROW_MAX_REF 8191
+#define ROW_COV_BITS 13   /* a record's word 0: rows covered (a Trail of up to 8191 bases) below the search's number */
 #define WIDE_BLOOM_WORDS 16384
 #ifndef WIDE_BLOOM_MIN_PATH
 #define WIDE_BLOOM_MIN_PATH 600   /* Trails that may grow beyond this many bases use it (config 5: search 122 / 113 / 107 / 104 / 103 / 104 ms at 2500 / 1500 / 1000 / 700 / 450 / 300) */
@@ -1007,24 +1008,24 @@ TALC_D void rows_shape() {
   const uint32_t n = (uint32_t)uni((int)X.refLen);
   uint32_t stride = 0, avail = 0;
   const uint32_t sn = (uint32_t)uni((int)X.searchNo) + 1u;
-  if (X.rowPool != nullptr && n <= (uint32_t)ROW_MAX_REF && sn < 0xFFFF0u) {   // (a wave's millionth search of a launch goes without)
+  if (X.rowPool != nullptr && n <= (uint32_t)ROW_MAX_REF && sn < 0x7FFF0u) {   // (a wave's half-millionth search of a launch goes without)
     stride = (n + 2u + 3u) & ~3u;
     avail = min((uint32_t)NBUF, (uint32_t)ROW_ARENA_INTS / stride);
   }
   X.rowStride = stride; X.rowAvail = avail;
-  X.searchNo = min(sn, 0xFFFF0u);
+  X.searchNo = min(sn, 0x7FFF0u);
 }
 TALC_D int* row_of(uint32_t buf) { return X.rowPool + (uint64_t)buf * X.rowStride; }
 // rows of the alignment matrix the record of buffer `buf` covers in the current search (0: none)
 TALC_D uint32_t row_covered(uint32_t buf) {
   const int* rec = row_of(buf);
   const uint32_t lo = (uint32_t)uni(rec[0]), hi = (uint32_t)uni(rec[(uint32_t)uni((int)X.refLen) + 1u]);
-  return (hi == (uint32_t)uni((int)X.launchStamp) && (lo >> 12) == (uint32_t)uni((int)X.searchNo)) ? (lo & 0xFFFu) : 0u;
+  return (hi == (uint32_t)uni((int)X.launchStamp) && (lo >> ROW_COV_BITS) == (uint32_t)uni((int)X.searchNo)) ? (lo & ((1u << ROW_COV_BITS) - 1u)) : 0u;
 }
 TALC_D void row_set_covered(uint32_t buf, uint32_t covered) {
   if (lane_id() == 0) {
     int* rec = row_of(buf);
-    rec[0] = (int)((X.searchNo << 12) | (covered & 0xFFFu));
+    rec[0] = (int)((X.searchNo << ROW_COV_BITS) | (covered & ((1u << ROW_COV_BITS) - 1u)));
     rec[X.refLen + 1u] = (int)X.launchStamp;
   }
 }
@@ -1957,7 +1958,7 @@ TALC_DNC void score_bridges_rows(int ib_, int nNew_, int m_, int tlen_, uint32_t
       if (myBuf < rowAvail) {   // row_covered, one Trail per lane
         const int TALC_AS1* rec = (const int TALC_AS1*)row_of(myBuf);
         const uint32_t lo = (uint32_t)rec[0], hi = (uint32_t)rec[n + 1];
-        myCov = (hi == stamp && (lo >> 12) == sno) ? (lo & 0xFFFu) : 0u;
+        myCov = (hi == stamp && (lo >> ROW_COV_BITS) == sno) ? (lo & ((1u << ROW_COV_BITS) - 1u)) : 0u;
       }
     }
     const int cnt = min(64, nNew - base);
@@ -1980,7 +1981,7 @@ TALC_DNC void score_bridges_rows(int ib_, int nNew_, int m_, int tlen_, uint32_t
   X.cells += ncells;
   WSYNC();
 }
-static_assert(ROW_MAX_REF <= 64 * 64 - 1, "the widest instance takes 64 columns per lane");
+static_assert(ROW_MAX_REF <= 64 * 128 - 1 && ROW_MAX_REF < (1 << ROW_COV_BITS), "the widest instance takes 128 columns per lane");
 
 TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_) {
   const DevParams& P = X.P;
@@ -1989,7 +1990,7 @@ TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_)
   const uint32_t bound = P.K + stepCounter + P.WINDOW;
   const int tlen = (int)min(bound, X.refLen);
   WSYNC();   // rows and stamps may have arrived by a copy, the Trails' last bases by lane 0
-  const uint32_t rowAvail = ((uint32_t)(len + 1) < 4096u) ? (uint32_t)uni((int)X.rowAvail) : 0u;
+  const uint32_t rowAvail = ((uint32_t)(len + 1) < (1u << ROW_COV_BITS)) ? (uint32_t)uni((int)X.rowAvail) : 0u;
   const int B = ((int)uni((int)X.refLen) + 63) >> 6;
   if (rowAvail == 0u || B <= 2) score_bridges_rows<2>(ib, nNew, len + 1, tlen, rowAvail);   // (no rows: every Trail from scratch, nw_score)
   else if (B <= 4) score_bridges_rows<4>(ib, nNew, len + 1, tlen, rowAvail);
@@ -1999,11 +2000,13 @@ TALC_DNC void score_bridges(int ib_, int nNew_, int len_, uint32_t stepCounter_)
   else if (B <= 16) score_bridges_rows<16>(ib, nNew, len + 1, tlen, rowAvail);
   else if (B <= 24) score_bridges_rows<24>(ib, nNew, len + 1, tlen, rowAvail);
   else if (B <= 32) score_bridges_rows<32>(ib, nNew, len + 1, tlen, rowAvail);
-  // (references of 2048-4095 bases: the row no longer fits the registers and these two instances spill — still a thousand
+  // (references of 2048-8191 bases: the row no longer fits the registers and these instances spill — still a thousand
   //  times less work than aligning every Trail of a 2 kb gap from scratch at every scoring, which is what made ONE walk of
   //  stress set 105 take 40 s)
   else if (B <= 48) score_bridges_rows<48>(ib, nNew, len + 1, tlen, rowAvail);
-  else score_bridges_rows<64>(ib, nNew, len + 1, tlen, rowAvail);
+  else if (B <= 64) score_bridges_rows<64>(ib, nNew, len + 1, tlen, rowAvail);
+  else if (B <= 96) score_bridges_rows<96>(ib, nNew, len + 1, tlen, rowAvail);
+  else score_bridges_rows<128>(ib, nNew, len + 1, tlen, rowAvail);
 }
 
 // A child of the generic step whose tip is an aim (checkAims, Trail.cpp:273-285): recordBridge (Explorer.cpp:1097-1101).
@@ -3717,7 +3720,7 @@ k_search(DevParams P, TableView T, SearchCaps C, const uint8_t* __restrict__ cod
   X.taskHeavy = E.heavy; X.heavyUpTo = (E.heavyRounds >= 0xFFFFu) ? 0xFFFFFFFFu : E.heavyRounds * gridDim.x;
   X.qi = 0; X.holding = 0u; X.stealSeq = 0u; X.moreCells = 0; X.moreSteps = 0;
   const uint32_t lingerMod = max(E.lingerMod, 1u);   // (5120 waves polling two words kept a memory channel busy: config 2 + 0.7 ms with nothing ever published)
-  X.searchNo = 16u;   // (stamps below 16 << 12 could be matrix values)
+  X.searchNo = 16u;   // (stamps below 16 << ROW_COV_BITS could be matrix values)
   {
     uint8_t* g = slot + C.o_gard;
     X.gScores = (double*)g; g += 8ull * (TCAP + 64);
@@ -4126,7 +4129,9 @@ k_test_dp(int mode, const uint8_t* a, int la, const uint8_t* b, int lb, int p0, 
       else if (B <= 24) sc = wave_nw_rows<24>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
       else if (B <= 32) sc = wave_nw_rows<32>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
       else if (B <= 48) sc = wave_nw_rows<48>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
-      else sc = wave_nw_rows<64>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 64) sc = wave_nw_rows<64>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else if (B <= 96) sc = wave_nw_rows<96>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
+      else sc = wave_nw_rows<128>(a, la, b, i0, m, 4, -3, -2, row, tlen, ncells);
       i0 = m;
       WSYNC();
       const int ex = nw_score(a, tlen, b, m, 4, -3, -2, true);

@@ -234,14 +234,14 @@ def test_device_edit_distance_and_lcs_beyond_4096_columns(gpu_pair):
 
 def test_device_alignment_rows_continued_equal_the_alignment_from_scratch(gpu_pair):
     """scoreBridges (Explorer.cpp:689-706): the device keeps every Trail's last alignment row over the whole reference and
-    adds the rows of the Trail's new bases (wave_nw_rows).  References of 30 to 4095 bases (every instance, 2 to 64
+    adds the rows of the Trail's new bases (wave_nw_rows).  References of 30 to 8191 bases (every instance, 2 to 128
     columns per lane), candidates growing by 1..17 bases from a first scoring of 21 or 70-200 bases, truncation windows of
     5-15: the kept row's entry against the
     alignment from scratch (nw_score, itself pinned to the oracle above) at every scoring."""
     rnd = random.Random(97)
     ctx = gpu_pair.ctx
     total = 0
-    for n in [30, 64, 65, 128, 129, 200, 260, 390, 520, 770, 1030, 1540, 2047, 2048, 2500, 3072, 3073, 4095]:
+    for n in [30, 64, 65, 128, 129, 200, 260, 390, 520, 770, 1030, 1540, 2047, 2048, 2500, 3072, 3073, 4095, 4096, 5000, 6144, 6145, 8191]:
         ref = [rnd.choice("ACGT") for _ in range(n)]
         cand = []
         for ch in ref[: min(n, 700)]:
@@ -262,7 +262,7 @@ def test_device_alignment_rows_continued_equal_the_alignment_from_scratch(gpu_pa
             assert got[5] == 0 and got[0] > 0
             assert got[1] == 0, (n, len(cand), first, step, "first differing length", int(got[2]))
             total += int(got[0])
-    assert total > 1000
+    assert total > 1300
 
 
 def test_device_seed_and_extension_matches_oracle(gpu_pair):
