@@ -63,7 +63,7 @@ def test_edge_anchors_run_by_other_waves_match_oracle(monkeypatch):
 
 def test_gaps_beyond_2047_bases_over_a_branching_graph_match_oracle():
     """300 reads of set 105 (K = 31, 40 % paralogs, reads to 20 kb): inner gaps of 2-3 kb walked with several Trails, whose
-    scoreBridges alignments are continued in the kept rows' two widest instances (references of 2048-4095 bases) — the walks
+    scoreBridges alignments are continued in the kept rows' wide instances (references of 2048-8191 bases) — the walks
     that took tens of seconds of one wave while every Trail was aligned from scratch."""
     pair, kw = _pair(105)
     bases, offs = pair.reads(0, 300)
